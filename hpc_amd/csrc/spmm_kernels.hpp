@@ -1,0 +1,372 @@
+// spmm_kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels for CSR SpMM.
+//
+// Replaces spmm_kernel_ref (PA4/workspace/src/spmm_ref.cu:3-17) and
+// SpmmOptKernel (PA4/workspace/src/spmm_opt.cu:9-35) of the reference.
+// Written for MI355X only: 64-lane wavefronts, 16-byte-per-lane global
+// accesses, ds_bpermute/readlane broadcast of the (col, val) pairs, many small
+// workgroups so the hardware dispatcher balances ragged rows over 256 CUs.
+//
+// Arithmetic contract (include/mi_spmm.h): every output element is the fp32
+// fma chain over the row's nonzeros in stored order starting from +0.0f --
+// exactly spmm_ref.cu:10-14 under the reference's fmad build.  The "rows"
+// kernel keeps that order (no cross-lane reduction at all: a lane owns its
+// output columns), so it is bit-identical to the oracle.  Only rows longer
+// than the split threshold go through "chunks" + "reduce", which sum
+// per-chunk chains in chunk order (deterministic, not bit-identical).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kBlockThreads = 256;  // 4 waves; 8 such blocks fill a CU's 32 wave slots
+
+struct RowsArgs {
+    const int32_t *row_ptr;
+    const int32_t *col_idx;
+    const float *vals;
+    const float *B;
+    float *C;
+    int64_t ldb;            // row pitch of B in floats
+    int64_t ldc;            // row pitch of C in floats
+    int32_t row0;           // first row of this launch's range
+    int32_t M;              // one past the last row of the range
+    int32_t N;
+    int32_t rows_per_block;
+    int32_t long_thr;       // rows with more nonzeros are left to the chunk path
+    int32_t nblk;           // gridDim.x (for the XCD remap)
+    int32_t flags;          // kFlagXcdRemap
+};
+
+struct Chunk {              // one <=long_chunk-nonzero piece of a long row
+    int32_t beg;            // first nonzero (index into col_idx/vals)
+    int32_t end;            // one past the last
+    int32_t slot;           // row of the partial-sum workspace it writes
+    int32_t row;            // CSR row it belongs to (debug / reduce cross-check)
+};
+
+struct LongRow {
+    int32_t row;
+    int32_t first_slot;
+    int32_t n_chunks;
+    int32_t pad;
+};
+
+enum : int32_t { kFlagXcdRemap = 4 };
+
+// Blocks b and b+8 land on the same XCD (round-robin dispatch; speed only,
+// never correctness -- cdna_hip_programming.md T1).  Give each XCD one
+// contiguous range of virtual blocks so neighbouring rows (which share B rows
+// in real graphs and stream adjacent col_idx/vals/C lines) meet in one L2.
+// Bijective for any nblk.
+__device__ __forceinline__ int xcd_remap(int b, int nblk)
+{
+    const int q = nblk >> 3, rem = nblk & 7;
+    const int x = b & 7, i = b >> 3;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
+}
+
+// Cache policy is a compile-time parameter (POL bit0: non-temporal C stores,
+// bit1: non-temporal col_idx/vals loads): as a run-time branch the optimiser
+// merges the two arms' identical accesses and drops the hint.
+enum : int { kPolNtStore = 1, kPolNtStream = 2 };
+
+template <int V> struct Vec;
+template <> struct Vec<4> {
+    typedef float4v T;
+    static __device__ __forceinline__ T zero() { return (T){0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ T load(const float *p) { return *reinterpret_cast<const T *>(p); }
+    template <bool NT> static __device__ __forceinline__ void store(float *p, T v)
+    {
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
+        else *reinterpret_cast<T *>(p) = v;
+    }
+    // one v_fma_f32 per component: exactly fmaf(b, a, acc)
+    static __device__ __forceinline__ T fma(T b, float a, T acc)
+    {
+        acc.x = __builtin_fmaf(b.x, a, acc.x);
+        acc.y = __builtin_fmaf(b.y, a, acc.y);
+        acc.z = __builtin_fmaf(b.z, a, acc.z);
+        acc.w = __builtin_fmaf(b.w, a, acc.w);
+        return acc;
+    }
+    static __device__ __forceinline__ T add(T a, T b)
+    {
+        return (T){a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    }
+};
+template <> struct Vec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ T load(const float *p) { return *p; }
+    template <bool NT> static __device__ __forceinline__ void store(float *p, T v)
+    {
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    }
+    static __device__ __forceinline__ T fma(T b, float a, T acc) { return __builtin_fmaf(b, a, acc); }
+    static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+};
+
+// Broadcast lane j of the LPR-lane group this lane belongs to.
+template <int LPR>
+__device__ __forceinline__ int group_bcast(int v, int j)
+{
+    if (LPR == 64) return __builtin_amdgcn_readlane(v, j);  // j is wave-uniform here
+    return __shfl(v, j, LPR);                               // ds_bpermute within the group
+}
+
+// Address of this lane's piece of B row c.
+//   narrow (WIDE=false): byte offset c*ldb*4 + col*4 fits 32 bits and both
+//   factors fit 24 bits (host-checked) -> one full-rate v_mad_u32_u24 and a
+//   global_load with an SGPR base;  wide: 64-bit arithmetic.
+template <bool WIDE>
+__device__ __forceinline__ const float *b_row_ptr(const float *B, int64_t ldb, uint32_t ldb_bytes,
+                                                  uint32_t col_bytes, int col, int c)
+{
+    if (WIDE) return B + (int64_t)c * ldb + col;
+    const uint32_t off = __umul24((uint32_t)c, ldb_bytes) + col_bytes;
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
+}
+
+// The fma chain of one segment [beg, end) of nonzeros for this lane's V
+// output columns.  Group-uniform control flow: all LPR lanes of a group see
+// the same beg/end.  The group fetches LPR (col, val) pairs with one
+// coalesced dword load each, then walks them in order in batches of UNROLL:
+// UNROLL independent B-row loads (V*4 bytes per lane, LPR*V*4 contiguous bytes
+// per row) are issued before the dependent fma chain consumes them, so each
+// wave keeps UNROLL requests of up to 1 KiB in flight.  Full batches carry no
+// predicates; the last partial batch of a fetch is predicated per load.
+template <int V, int LPR, int UNROLL, bool WIDE, bool NT_STREAM>
+__device__ __forceinline__ typename Vec<V>::T
+segment_chain(const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+              const float *__restrict__ B, int64_t ldb, int col, int beg, int end,
+              int lig)
+{
+    typedef typename Vec<V>::T T;
+    T acc = Vec<V>::zero();
+    const uint32_t ldb_bytes = (uint32_t)ldb * 4u, col_bytes = (uint32_t)col * 4u;
+    for (int k0 = beg; k0 < end; k0 += LPR) {
+        const int k = k0 + lig;
+        int ci = 0;
+        float av = 0.f;
+        if (k < end) {
+            if (NT_STREAM) {
+                ci = __builtin_nontemporal_load(col_idx + k);
+                av = __builtin_nontemporal_load(vals + k);
+            } else {
+                ci = col_idx[k];
+                av = vals[k];
+            }
+        }
+        const int avi = __float_as_int(av);
+        const int cnt = min(LPR, end - k0);
+        int j = 0;
+        for (; j + UNROLL <= cnt; j += UNROLL) {
+            T b[UNROLL];
+            float a[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int c = group_bcast<LPR>(ci, j + u);
+                a[u] = __int_as_float(group_bcast<LPR>(avi, j + u));
+                b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc = Vec<V>::fma(b[u], a[u], acc);
+        }
+        if (UNROLL > 1 && j < cnt) {
+            T b[UNROLL];
+            float a[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u) {
+                const int jj = j + u;  // < LPR because UNROLL divides LPR
+                const int c = group_bcast<LPR>(ci, jj);
+                a[u] = __int_as_float(group_bcast<LPR>(avi, jj));
+                b[u] = Vec<V>::zero();
+                if (jj < cnt) b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
+            }
+            // slots past the segment carry a = +0 (lane k >= end loaded nothing) and
+            // b = +0: fma(0, 0, acc) == acc bit for bit (acc is never -0: it starts
+            // at +0 and a sum is -0 only when both addends are)
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u) acc = Vec<V>::fma(b[u], a[u], acc);
+        }
+    }
+    return acc;
+}
+
+// ---- rows kernel: exact-order path -------------------------------------------
+// grid.x = ceil(M / rows_per_block), grid.y = ceil(N / (LPR*V)) column tiles,
+// block = 256 threads = 256/LPR lane groups; a group owns one row at a time.
+template <int V, int LPR, int UNROLL, bool WIDE, int POL>
+__global__ __launch_bounds__(kBlockThreads) void spmm_rows(RowsArgs a)
+{
+    constexpr int GPB = kBlockThreads / LPR;  // groups per block
+    const int tid = threadIdx.x;
+    const int g = tid / LPR;
+    const int lig = tid % LPR;
+    const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(blockIdx.x, a.nblk) : (int)blockIdx.x;
+    const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
+    const bool col_ok = col_raw < a.N;
+    const int col = col_ok ? col_raw : a.N - V;  // lanes past N load a valid column and store nothing
+
+    const int r0 = a.row0 + vb * a.rows_per_block;
+    const int r1 = min(a.M, r0 + a.rows_per_block);
+    for (int r = r0 + g; r < r1; r += GPB) {
+        int beg = a.row_ptr[r];
+        int end = a.row_ptr[r + 1];
+        if (LPR == 64) {  // whole wave on one row: make the bounds scalar
+            beg = __builtin_amdgcn_readfirstlane(beg);
+            end = __builtin_amdgcn_readfirstlane(end);
+        }
+        if (end - beg > a.long_thr) continue;  // chunk path owns this row
+        typename Vec<V>::T acc = segment_chain<V, LPR, UNROLL, WIDE, (POL & kPolNtStream) != 0>(
+            a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
+        if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)r * a.ldc + col, acc);
+    }
+}
+
+// ---- chunks kernel: long rows, one lane group per chunk ----------------------
+struct ChunkArgs {
+    const Chunk *chunks;
+    const int32_t *col_idx;
+    const float *vals;
+    const float *B;
+    float *partials;       // [n_chunks][ldp]
+    int64_t ldb;
+    int64_t ldp;
+    int32_t n_chunks;
+    int32_t N;
+    int32_t flags;
+};
+
+template <int V, int LPR, int UNROLL, bool WIDE>
+__global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
+{
+    constexpr int GPB = kBlockThreads / LPR;
+    const int tid = threadIdx.x;
+    const int g = tid / LPR;
+    const int lig = tid % LPR;
+    const int ch = (int)blockIdx.x * GPB + g;
+    if (ch >= a.n_chunks) return;
+    const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
+    const bool col_ok = col_raw < a.N;
+    const int col = col_ok ? col_raw : a.N - V;
+    Chunk c = a.chunks[ch];
+    int beg = c.beg, end = c.end;
+    if (LPR == 64) {
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    typename Vec<V>::T acc =
+        segment_chain<V, LPR, UNROLL, WIDE, true>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
+    if (col_ok) Vec<V>::template store<false>(a.partials + (int64_t)c.slot * a.ldp + col, acc);
+}
+
+// ---- reduce kernel: C[row] = ((p0 + p1) + p2) + ...  in chunk order ----------
+struct ReduceArgs {
+    const LongRow *rows;
+    const float *partials;
+    float *C;
+    int64_t ldp;
+    int64_t ldc;
+    int32_t n_long;
+    int32_t N;
+    int32_t flags;
+};
+
+template <int V>
+__global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a)
+{
+    const int vec_per_row = (a.N + V - 1) / V;
+    const int64_t t = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    const int64_t lr = t / vec_per_row;
+    if (lr >= a.n_long) return;
+    const int col = (int)(t % vec_per_row) * V;
+    const LongRow L = a.rows[lr];
+    const float *p = a.partials + (int64_t)L.first_slot * a.ldp + col;
+    typename Vec<V>::T acc = Vec<V>::load(p);
+    for (int i = 1; i < L.n_chunks; ++i) acc = Vec<V>::add(acc, Vec<V>::load(p + (int64_t)i * a.ldp));
+    Vec<V>::template store<true>(a.C + (int64_t)L.row * a.ldc + col, acc);
+}
+
+// ---- CSR sanity: column range (an out-of-range column would fault the GPU) ----
+__global__ __launch_bounds__(kBlockThreads) void csr_check_cols(const int32_t *__restrict__ col_idx,
+                                                               int64_t nnz, int32_t num_cols,
+                                                               unsigned int *bad)
+{
+    unsigned int local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x; i < nnz;
+         i += (int64_t)gridDim.x * kBlockThreads) {
+        const int32_t c = col_idx[i];
+        local |= (c < 0 || c >= num_cols) ? 1u : 0u;
+    }
+    if (__any(local)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+    }
+}
+
+// ---- validators: valid.cu:3-20 of the reference ------------------------------
+// mode 0: validate_float  |(y - y2)/y| > 1e-2   (float quotient, double compare)
+// mode 1: validate_int    y != y2
+// mode 2: bit patterns differ (parity tests) + max |a-b|
+__global__ __launch_bounds__(kBlockThreads) void compare_kernel(const void *ya, const void *yb,
+                                                               int64_t n, int mode,
+                                                               unsigned long long *count,
+                                                               unsigned int *maxabs_bits)
+{
+    unsigned long long local = 0;
+    float lmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlockThreads) {
+        if (mode == 0) {
+            const float r = ((const float *)ya)[i], s = ((const float *)yb)[i];
+            const float q = __builtin_fabsf((r - s) / r);  // IEEE division (no fast-math here)
+            if ((double)q > 1e-2) ++local;
+        } else if (mode == 1) {
+            if (((const int32_t *)ya)[i] != ((const int32_t *)yb)[i]) ++local;
+        } else {
+            const unsigned int u = ((const unsigned int *)ya)[i], w = ((const unsigned int *)yb)[i];
+            if (u != w) {
+                ++local;
+                const float d = __builtin_fabsf(__uint_as_float(u) - __uint_as_float(w));
+                if (d == d) lmax = fmaxf(lmax, d);
+                else lmax = __builtin_inff();  // NaN involved: report as inf
+            }
+        }
+    }
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        local += __shfl_down(local, off, 64);
+        lmax = fmaxf(lmax, __shfl_down(lmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (local) atomicAdd(count, local);
+        if (maxabs_bits && lmax > 0.f) atomicMax(maxabs_bits, __float_as_uint(lmax));  // non-negative floats order as uints
+    }
+}
+
+// ---- all-gather unpack: staging[G][rows][n_loc] -> C[rows][ldc] --------------
+template <int V>
+__global__ __launch_bounds__(kBlockThreads) void unpack_gathered(const float *__restrict__ staging,
+                                                                float *__restrict__ C, int64_t rows,
+                                                                int32_t G, int32_t n_loc, int64_t ldc)
+{
+    const int vpr = n_loc / V;  // vectors per (rank, row)
+    const int64_t total = rows * (int64_t)G * vpr;
+    for (int64_t t = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * kBlockThreads) {
+        // iterate in OUTPUT order (row, rank, vec) so stores are contiguous
+        const int v = (int)(t % vpr);
+        const int64_t rg = t / vpr;
+        const int g = (int)(rg % G);
+        const int64_t r = rg / G;
+        const float *src = staging + ((int64_t)g * rows + r) * n_loc + v * V;
+        float *dst = C + r * ldc + (int64_t)g * n_loc + v * V;
+        Vec<V>::template store<false>(dst, Vec<V>::load(src));
+    }
+}
+
+}  // namespace mi

@@ -1,0 +1,127 @@
+"""Column-sharded multi-GPU SpMM: C[:, g*n : (g+1)*n] = A * B[:, g*n : (g+1)*n] on GPU g,
+then an all-gather of the C column blocks (RCCL over xGMI) so every rank holds row-major C.
+
+The reference has no multi-GPU code; what must hold is "same C as one GPU":
+column blocks are independent, every element is produced by the same kernel in the same
+order, so the gathered C is bit-identical to the 1-GPU C.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL).  A is replicated, each rank
+keeps its B slice resident as a contiguous K x n_loc array.  The exchange is pipelined by row
+panels: while panel p's column blocks travel, panel p+1's rows are being computed:
+
+    compute stream :  rows(p0) | rows(p1) | rows(p2) | ...
+    comm stream    :           | gather(p0) unpack(p0) | gather(p1) unpack(p1) | ...
+
+all_gather_into_tensor delivers rank-major blocks staging[G][rows][n_loc] (an all-gather
+concatenates contiguous per-rank buffers -- SURVEY.md H4); `unpack` writes them into the
+row-major C[rows][G*n_loc] the interface promises (a HIP kernel on the GPU path).
+
+The class is device-agnostic host logic: the local operator and the unpack step are passed in.
+Product use (bench.py): op = hpc_amd.SpMMOpt, unpack = hpc_amd.spmm.unpack_gathered.  The
+world_size-2 gloo tests on CPU drive the same schedule with test doubles.
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+
+def column_block(N_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """[col0, col1) owned by `rank`: equal blocks (N_total must divide by world, like the
+    north-star configuration N = 1024 over 8 GPUs)."""
+    if N_total % world:
+        raise ValueError(f"N={N_total} does not divide over {world} ranks")
+    n = N_total // world
+    return rank * n, (rank + 1) * n
+
+
+def row_panels(M: int, n_panels: int, align: int = 256) -> List[Tuple[int, int]]:
+    """Split [0, M) into at most n_panels contiguous panels whose sizes are multiples of `align`
+    rows (except the last).  The first panel is never empty when M > 0."""
+    if M <= 0:
+        return []
+    n_panels = max(1, int(n_panels))
+    per = -(-M // n_panels)
+    per = -(-per // align) * align
+    out = []
+    r = 0
+    while r < M:
+        e = min(M, r + per)
+        out.append((r, e))
+        r = e
+    return out
+
+
+@dataclass
+class ShardLayout:
+    M: int
+    n_loc: int
+    world: int
+    rank: int
+
+    @property
+    def N_total(self) -> int:
+        return self.n_loc * self.world
+
+    @property
+    def col0(self) -> int:
+        return self.rank * self.n_loc
+
+
+class ColumnShardedSpMM:
+    """run(B_loc, C_loc, C_full): C_loc[M][n_loc] = A * B_loc (this rank's block, scratch the
+    caller owns), C_full[M][G*n_loc] = all blocks, row-major, identical on every rank."""
+
+    def __init__(self, op, layout: ShardLayout, unpack: Callable, n_panels: int = 8,
+                 group=None, use_streams: Optional[bool] = None):
+        self.op = op
+        self.layout = layout
+        self.unpack = unpack
+        self.group = group
+        self.panels = row_panels(layout.M, n_panels)
+        self.use_streams = use_streams
+        self._staging = None
+        self._streams = None
+
+    def _ensure_buffers(self, like):
+        import torch
+
+        L = self.layout
+        rows_max = max((e - b for b, e in self.panels), default=0)
+        need = L.world * rows_max * L.n_loc
+        if self._staging is None or self._staging[0].numel() < need or self._staging[0].device != like.device:
+            self._staging = [torch.empty(need, dtype=like.dtype, device=like.device) for _ in range(2)]
+        if self.use_streams is None:
+            self.use_streams = like.is_cuda
+        if self.use_streams and self._streams is None:
+            self._streams = torch.cuda.Stream(device=like.device)
+
+    def run(self, B_loc, C_loc, C_full):
+        import torch
+        import torch.distributed as dist
+
+        L = self.layout
+        if L.world == 1:
+            # nothing to exchange: the local block IS C
+            self.op.run_rows(B_loc, L.n_loc, C_full, L.N_total, 0, L.M)
+            return
+        self._ensure_buffers(C_loc)
+        comm = self._streams
+        main = torch.cuda.current_stream() if self.use_streams else None
+        if self.use_streams:
+            comm.wait_stream(main)  # staging/C_full reuse across calls
+        for p, (r0, r1) in enumerate(self.panels):
+            rows = r1 - r0
+            self.op.run_rows(B_loc, L.n_loc, C_loc, L.n_loc, r0, r1)
+            src = C_loc.view(-1)[r0 * L.n_loc: r1 * L.n_loc]
+            stage = self._staging[p & 1][: L.world * rows * L.n_loc]
+            if self.use_streams:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    dist.all_gather_into_tensor(stage, src, group=self.group)
+                    self.unpack(stage, C_full.view(-1)[r0 * L.N_total:], rows, L.world, L.n_loc, L.N_total)
+            else:
+                dist.all_gather_into_tensor(stage, src, group=self.group)
+                self.unpack(stage, C_full.view(-1)[r0 * L.N_total:], rows, L.world, L.n_loc, L.N_total)
+        if self.use_streams:
+            main.wait_stream(comm)

@@ -1,0 +1,206 @@
+"""Synthetic CSR inputs for the BASELINE.json configurations.
+
+The reference reads 13 course graphs that are not in its repository
+(PA4/workspace/script/run_all.sh:3,10) and fills A's values, B and C with
+cuRAND N(0, 0.1) (include/data.h:31, seed 123 test/main.cpp:20).  Here:
+
+  * structure: int32 row_ptr[M+1], col_idx[nnz] sorted ascending and distinct
+    inside a row, 0-based, square (K = M) like the reference's adjacency;
+  * values: fp32 N(0, 0.1) from numpy's counter-based Philox generator keyed by
+    (seed, stream) -- the distribution of the reference, not cuRAND's bit stream
+    (XORWOW is not reproducible without cuRAND);
+  * seeds: structure 123 (echoing main.cpp:20), vals 124, B 125.
+
+Everything is generated on the host with numpy and is a pure function of its
+arguments, so the CPU container, the GPU box and every rank build identical
+inputs without shipping files.
+"""
+import numpy as np
+
+SEED_STRUCT = 123
+SEED_VALS = 124
+SEED_B = 125
+
+
+def _rng(seed, stream=0):
+    return np.random.Generator(np.random.Philox(key=[int(seed), int(stream)]))
+
+
+def normal_f32(n, seed, stream=0, mean=0.0, std=0.1, chunk=1 << 24):
+    """fp32 N(mean, std) of length n; chunked so peak host memory stays ~2x the output."""
+    out = np.empty(int(n), dtype=np.float32)
+    g = _rng(seed, stream)
+    for s in range(0, int(n), chunk):
+        e = min(int(n), s + chunk)
+        out[s:e] = g.standard_normal(e - s, dtype=np.float32) * np.float32(std) + np.float32(mean)
+    return out
+
+
+def _finish_rows(M, K, deg, g):
+    """Random distinct sorted columns per row for the given degree vector."""
+    deg = np.minimum(deg.astype(np.int64), K)
+    row_ptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(deg, out=row_ptr[1:])
+    nnz = int(row_ptr[-1])
+    rows = np.repeat(np.arange(M, dtype=np.int64), deg)
+    cols = g.integers(0, K, size=nnz, dtype=np.int64)
+    key = rows * np.int64(K) + cols
+    key.sort()
+    # drop duplicate (row, col) pairs: columns stay distinct inside a row
+    keep = np.ones(nnz, dtype=bool)
+    keep[1:] = key[1:] != key[:-1]
+    key = key[keep]
+    rows = key // np.int64(K)
+    cols = (key - rows * np.int64(K)).astype(np.int32)
+    counts = np.bincount(rows, minlength=M).astype(np.int64)
+    row_ptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(counts, out=row_ptr[1:])
+    assert row_ptr[-1] <= np.iinfo(np.int32).max
+    return row_ptr.astype(np.int32), cols
+
+
+def csr_uniform(M, deg_lo, deg_hi, K=None, seed=SEED_STRUCT):
+    """Row degree ~ Uniform{deg_lo..deg_hi}, uniform random columns.
+    C0: M=1024, 0..32 (mean 16, empty rows included).  C1: M=2^20, 16..48 (mean 32)."""
+    K = M if K is None else K
+    g = _rng(seed, 0)
+    deg = g.integers(deg_lo, deg_hi + 1, size=M, dtype=np.int64)
+    return _finish_rows(M, K, deg, g)
+
+
+def csr_powerlaw(M, mean_deg=32.0, max_deg=4096, alpha=1.5, K=None, seed=SEED_STRUCT):
+    """C2: degree_i = min(max_deg, floor(d_min * u^(-1/alpha))), d_min solved (bisection on
+    this very sample) so that the mean degree is mean_deg; rows are NOT sorted by degree."""
+    K = M if K is None else K
+    g = _rng(seed, 1)
+    u = g.random(M)
+    w = u ** (-1.0 / alpha)
+    lo, hi = 0.01, float(mean_deg)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        m = np.minimum(max_deg, np.floor(mid * w)).mean()
+        if m < mean_deg:
+            lo = mid
+        else:
+            hi = mid
+    deg = np.minimum(max_deg, np.floor(hi * w)).astype(np.int64)
+    return _finish_rows(M, K, deg, g)
+
+
+def csr_block_dense(M, rows_per_block=16, run_lo=64, run_hi=128, max_runs=2, K=None, seed=SEED_STRUCT):
+    """C4: rows in blocks of `rows_per_block` share 1..max_runs aligned contiguous column runs
+    of 64..128 columns (run start and length multiples of 64/..: aligned to 64); every row of a
+    block holds every column of the block's runs (>= 64 contiguous nonzeros per row)."""
+    K = M if K is None else K
+    g = _rng(seed, 2)
+    nb = (M + rows_per_block - 1) // rows_per_block
+    n_runs = g.integers(1, max_runs + 1, size=nb)
+    ptr = np.zeros(M + 1, dtype=np.int64)
+    cols_blocks = []
+    lens = np.zeros(nb, dtype=np.int64)
+    align = 64
+    for b in range(nb):
+        runs = []
+        for _ in range(int(n_runs[b])):
+            length = int(g.integers(run_lo // align, run_hi // align + 1)) * align
+            start = int(g.integers(0, max(1, (K - length) // align + 1))) * align
+            runs.append((start, length))
+        runs.sort()
+        # merge overlaps so columns stay distinct and ascending
+        merged = []
+        for s, l in runs:
+            if merged and s <= merged[-1][0] + merged[-1][1]:
+                ps, pl = merged[-1]
+                merged[-1] = (ps, max(pl, s + l - ps))
+            else:
+                merged.append((s, l))
+        c = np.concatenate([np.arange(s, min(K, s + l), dtype=np.int32) for s, l in merged])
+        cols_blocks.append(c)
+        lens[b] = c.size
+    deg = np.repeat(lens, rows_per_block)[:M]
+    np.cumsum(deg, out=ptr[1:])
+    col_idx = np.empty(int(ptr[-1]), dtype=np.int32)
+    for b in range(nb):
+        r0 = b * rows_per_block
+        r1 = min(M, r0 + rows_per_block)
+        c = cols_blocks[b]
+        col_idx[ptr[r0]:ptr[r1]] = np.tile(c, r1 - r0)
+    assert ptr[-1] <= np.iinfo(np.int32).max
+    return ptr.astype(np.int32), col_idx
+
+
+def csr_block_dense_fast(M, rows_per_block=16, K=None, seed=SEED_STRUCT):
+    """Vectorised C4 generator for M = 2^20: one or two aligned runs of 64 or 128 columns per
+    16-row block (same family as csr_block_dense, no Python loop over blocks)."""
+    K = M if K is None else K
+    g = _rng(seed, 3)
+    nb = (M + rows_per_block - 1) // rows_per_block
+    align = 64
+    slots = K // align
+    n_runs = g.integers(1, 3, size=nb)
+    len1 = g.integers(1, 3, size=nb) * align
+    len2 = g.integers(1, 3, size=nb) * align
+    s1 = g.integers(0, slots - 4, size=nb) * align
+    gap = g.integers(0, slots // 2, size=nb) * align
+    s2 = np.minimum(s1 + len1 + gap, (slots - 2) * align)   # second run never overlaps the first
+    s2 = np.maximum(s2, s1 + len1)
+    len2 = np.where(n_runs == 2, len2, 0)
+    blk_len = (len1 + len2).astype(np.int64)
+    deg = np.repeat(blk_len, rows_per_block)[:M]
+    ptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(deg, out=ptr[1:])
+    nnz = int(ptr[-1])
+    assert nnz <= np.iinfo(np.int32).max
+    rows = np.repeat(np.arange(M, dtype=np.int64), deg)
+    pos = np.arange(nnz, dtype=np.int64) - ptr[:-1][rows]      # position inside the row
+    b = rows // rows_per_block
+    in_first = pos < len1[b]
+    col = np.where(in_first, s1[b] + pos, s2[b] + (pos - len1[b]))
+    return ptr.astype(np.int32), col.astype(np.int32)
+
+
+def make_values(nnz, seed=SEED_VALS):
+    return normal_f32(nnz, seed, 0)
+
+
+def make_dense(K, N, seed=SEED_B):
+    return normal_f32(int(K) * int(N), seed, 0).reshape(int(K), int(N))
+
+
+def config(name, N=None, M=None):
+    """(row_ptr, col_idx, vals, B, meta) for BASELINE.json configs C0..C4 (optionally down-sized)."""
+    name = name.upper()
+    if name == "C0":
+        M = 1024 if M is None else M
+        N = 32 if N is None else N
+        ptr, idx = csr_uniform(M, 0, 32)
+    elif name == "C1":
+        M = (1 << 20) if M is None else M
+        N = 128 if N is None else N
+        ptr, idx = csr_uniform(M, 16, 48)
+    elif name == "C2":
+        M = (1 << 20) if M is None else M
+        N = 128 if N is None else N
+        ptr, idx = csr_powerlaw(M, 32.0, 4096)
+    elif name == "C4":
+        M = (1 << 20) if M is None else M
+        N = 256 if N is None else N
+        ptr, idx = csr_block_dense_fast(M)
+    else:
+        raise ValueError(name)
+    vals = make_values(idx.size)
+    B = make_dense(M, N)
+    deg = np.diff(ptr)
+    meta = {
+        "config": name, "M": int(M), "K": int(M), "N": int(N), "nnz": int(idx.size),
+        "deg_mean": float(deg.mean()) if M else 0.0, "deg_max": int(deg.max()) if M else 0,
+        "deg_p50": float(np.percentile(deg, 50)) if M else 0.0, "deg_p99": float(np.percentile(deg, 99)) if M else 0.0,
+    }
+    return ptr, idx, vals, B, meta
+
+
+def bytes_model(M, K, N, nnz):
+    """algorithmic (gather-model) bytes, compulsory lower bound, flops."""
+    alg = 8 * nnz + 4 * (M + 1) + 4 * N * nnz + 4 * M * N
+    low = 8 * nnz + 4 * (M + 1) + 4 * K * N + 4 * M * N
+    return {"bytes_alg": int(alg), "bytes_min": int(low), "flops": int(2 * nnz * N)}

@@ -1,0 +1,150 @@
+/*
+ * mi_spmm.h -- C ABI of the MI355X-native CSR SpMM  (C = A_csr * B_dense).
+ *
+ * This is the drop-in boundary for the liblaf/hpc PA4 operator.  The
+ * reference has no FFI of its own: its boundary is the abstract C++ class
+ * `SpMM` (PA4/workspace/include/spmm_base.h:8-46) with
+ *      SpMM(CSR *g, int feat_in)
+ *      virtual void preprocess(float *vin, float *vout)
+ *      virtual void run(float *vin, float *vout)
+ * implemented by SpMMRef / SpMMOpt / SpMMCuSparse.  Each entry point below
+ * names the reference member it replaces; include/spmm_adapter.hpp wraps them
+ * back into a class with exactly that shape, INTEGRATION.md shows the binding.
+ *
+ * Conventions (all from the reference):
+ *   - every buffer is a DEVICE pointer owned by the caller
+ *     (test/test_spmm.cu:16-20, test/main.cpp:11-14); the handle never frees
+ *     them and owns only what preprocess allocates;
+ *   - CSR: int32 row_ptr[num_v+1], int32 col_idx[nnz], fp32 vals[nnz],
+ *     0-based (src/spmm_cusparse.cu:6-9), row_ptr[num_v] == nnz
+ *     (src/data.cu:40-45), column order inside a row unspecified;
+ *   - dense B (vin) and C (vout) are row-major fp32 with leading dimension
+ *     feat_in (src/spmm_cusparse.cu:11-15); the reference is square (K = M);
+ *   - run() leaves vout = A*vin (overwrite, like spmm_ref.cu:15 and cuSPARSE
+ *     beta = 0, include/spmm_cusparse.h:22), is idempotent, asynchronous on
+ *     the given stream and performs no host synchronisation;
+ *   - arithmetic per output element: fp32 fused multiply-add chain over the
+ *     row's nonzeros in stored order starting from +0.0f (spmm_ref.cu:10-14
+ *     under the reference's nvcc --use_fast_math build).  Rows handled by the
+ *     exact-order kernels are bit-identical to that chain; rows longer than
+ *     the split threshold are summed in chunks (tolerance: DESIGN.md).
+ *
+ * Errors: the reference aborts (include/util.h:63-84).  The C ABI never
+ * aborts: every function returns 0 on success or a negative MI_SPMM_E* /
+ * positive hipError_t code; the C++ adapter restores abort-on-error.
+ *
+ * Threading: a handle is not thread-safe; use one handle per host thread and
+ * device (the reference is single-threaded with globals, src/util.cu:3-12).
+ */
+#ifndef MI_SPMM_H
+#define MI_SPMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_SPMM_ABI_VERSION 1
+
+/* error codes (negative = ours, positive = hipError_t passed through) */
+#define MI_SPMM_OK            0
+#define MI_SPMM_EINVAL       -1  /* bad argument (NULL pointer, negative size) */
+#define MI_SPMM_ENOMEM       -2  /* host or device allocation failed */
+#define MI_SPMM_ESTATE       -3  /* run() before preprocess(), bad handle */
+#define MI_SPMM_ECSR         -4  /* row_ptr not monotone / row_ptr[M] != nnz / column out of range */
+#define MI_SPMM_EUNSUPPORTED -5  /* option or shape not supported */
+#define MI_SPMM_ENODEVICE    -6  /* no gfx950 device / HIP runtime unusable */
+
+typedef struct mi_spmm_handle mi_spmm_handle;
+
+/* Replaces SpMM::SpMM(CSR *g, int feat_in) and struct CSR
+ * (spmm_base.h:14-21, util.h:120-129).  Stores the five scalars and three
+ * device pointers; touches no device memory.  num_cols = K (rows of B); the
+ * reference always has K = num_v. */
+int mi_spmm_create(mi_spmm_handle **out,
+                   const int32_t *d_row_ptr, const int32_t *d_col_idx,
+                   const float *d_vals,
+                   int32_t num_v, int32_t num_cols, int64_t nnz,
+                   int32_t feat_in);
+
+/* Replaces SpMM::set_feat (spmm_base.h:26-29).  Invalidates preprocess. */
+int mi_spmm_set_feat(mi_spmm_handle *h, int32_t feat_in);
+
+/* Replaces SpMMOpt::preprocess(vin, vout) (src/spmm_opt.cu:37-69): reads
+ * row_ptr (device -> host), validates it, classifies rows, builds the launch
+ * plan and the long-row chunk table, allocates the handle-owned workspace.
+ * May synchronise the device (the reference's does: cudaMemcpy D2H, :39).
+ * Unlike the reference it does NOT need vout zeroed and does not touch it. */
+int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout);
+
+/* Replaces SpMMOpt::run(vin, vout) (src/spmm_opt.cu:71-75).  stream is a
+ * hipStream_t (NULL = the null stream the reference uses). */
+int mi_spmm_run(mi_spmm_handle *h, const float *d_vin, float *d_vout,
+                void *stream);
+
+/* Same with explicit row pitches (in floats) for B and C: lets a column shard
+ * read its slice of a wider row-major B and write its slice of a wider C
+ * (multi-GPU column sharding; no reference counterpart). */
+int mi_spmm_run_ld(mi_spmm_handle *h, const float *d_vin, int64_t ldb,
+                   float *d_vout, int64_t ldc, void *stream);
+
+/* Same for the row range [row_begin, row_end) only (d_vout is still the base of
+ * the full-height C): lets the multi-GPU driver compute C in row panels and
+ * overlap each panel's all-gather with the next panel's kernel.  Rows longer
+ * than the split threshold are all produced by the call with row_begin == 0. */
+int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb,
+                     float *d_vout, int64_t ldc, int32_t row_begin,
+                     int32_t row_end, void *stream);
+
+/* Replaces SpMMOpt::~SpMMOpt (include/spmm_opt.h:18-20). */
+int mi_spmm_destroy(mi_spmm_handle *h);
+
+/* Message for a code returned by any function here. */
+const char *mi_spmm_strerror(int code);
+
+/* Tuning / introspection.  Keys (all int64):
+ *   "long_row_threshold"  rows with more nonzeros are split into chunks
+ *   "long_row_chunk"      chunk length in nonzeros
+ *   "unroll"              B-row loads in flight per lane group (4,8,16)
+ *   "rows_per_block"      rows handled by one 256-thread workgroup
+ *   "xcd_remap"           0/1: contiguous row ranges per XCD
+ *   "nt_store"            0/1: non-temporal stores of C
+ *   "nt_stream"           0/1: non-temporal loads of col_idx/vals
+ *   "block_path"          0/1: allow the block-dense MFMA path
+ * set before preprocess; get any time.  Read-only keys after preprocess:
+ *   "n_long_rows", "n_chunks", "workspace_bytes", "n_launches",
+ *   "n_block_groups", "lanes_per_row", "preprocess_us" */
+int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t value);
+int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value);
+
+/* Replaces valid(float*, float*, int) / validate_float
+ * (src/valid.cu:3-11,36-51): counts elements with
+ * |(y[i]-y2[i])/y[i]| > 1e-2 on the device.  n is 64-bit here (the
+ * reference's int overflows at M*N >= 2^31). */
+int mi_spmm_valid_float(const float *d_y, const float *d_y2, int64_t n,
+                        int64_t *bad_out, void *stream);
+/* Replaces valid(int*, int*, int) / validate_int (src/valid.cu:13-34). */
+int mi_spmm_valid_int(const int32_t *d_y, const int32_t *d_y2, int64_t n,
+                      int64_t *bad_out, void *stream);
+
+/* Exact comparison helpers for parity tests: number of fp32 elements whose
+ * BIT PATTERNS differ, and max |a-b| (both computed on the device). */
+int mi_spmm_count_bitdiff(const float *d_a, const float *d_b, int64_t n,
+                          int64_t *ndiff_out, float *maxabs_out, void *stream);
+
+/* Column-shard plumbing for the multi-GPU all-gather.
+ * RCCL all-gather delivers rank-major blocks  staging[G][rows][n_loc];
+ * this writes them into row-major C[rows][ldc] at column g*n_loc. */
+int mi_spmm_unpack_gathered(const float *d_staging, float *d_C, int64_t rows,
+                            int32_t n_ranks, int32_t n_loc, int64_t ldc,
+                            void *stream);
+
+/* Library/ABI identification. */
+int mi_spmm_abi_version(void);
+const char *mi_spmm_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SPMM_H */

@@ -1,0 +1,228 @@
+"""ctypes front end of the oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  hpc_amd/ never does (tests/test_no_oracle_in_product.py checks).
+
+  liboracle.so                      CPU restatement (oracle/spmm_oracle.c)
+  _ref/libspmm_ref_gfx950.so        the reference's own kernels compiled by hipcc from
+                                    /root/reference in place (oracle/Makefile `_ref`);
+                                    needs a GPU to run; prebuilt file travels to the GPU box
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+REF_LIB = os.path.join(_HERE, "_ref", "libspmm_ref_gfx950.so")
+
+_lib = None
+_ref = None
+
+
+def build(ref=True):
+    """Compile the C restatement and (when /root/reference is present) oracle/_ref."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if ref:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_ref"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build(ref=False)
+        L = C.CDLL(LIB)
+        P = C.c_void_p
+        L.oracle_spmm_ref.argtypes = [P, P, P, P, P, C.c_int32, C.c_int32]
+        L.oracle_spmm_ref.restype = None
+        L.oracle_spmm_nofma.argtypes = [P, P, P, P, P, C.c_int32, C.c_int32]
+        L.oracle_spmm_nofma.restype = None
+        L.oracle_spmm_omp.argtypes = [P, P, P, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.oracle_spmm_omp.restype = None
+        L.oracle_spmm_f64.argtypes = [P, P, P, P, P, P, C.c_int32, C.c_int32]
+        L.oracle_spmm_f64.restype = None
+        L.oracle_valid_float.argtypes = [P, P, C.c_int64]
+        L.oracle_valid_float.restype = C.c_int64
+        L.oracle_valid_int.argtypes = [P, P, C.c_int64]
+        L.oracle_valid_int.restype = C.c_int64
+        L.oracle_validation_passes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+        L.oracle_validation_passes.restype = C.c_int
+        L.oracle_num_threads.restype = C.c_int
+        L.oracle_fnv1a64.argtypes = [P, C.c_int64]
+        L.oracle_fnv1a64.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _csr(ptr, idx, val):
+    ptr = np.ascontiguousarray(ptr, dtype=np.int32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float32)
+    return ptr, idx, val
+
+
+def spmm_ref(ptr, idx, val, vin, feat=None):
+    """spmm_kernel_ref restated (serial, reference loop order)."""
+    ptr, idx, val = _csr(ptr, idx, val)
+    vin = np.ascontiguousarray(vin, dtype=np.float32)
+    num_v = ptr.size - 1
+    feat = vin.shape[1] if feat is None else feat
+    out = np.empty((num_v, feat), dtype=np.float32)
+    lib().oracle_spmm_ref(_p(ptr), _p(idx), _p(val), _p(vin), _p(out), num_v, feat)
+    return out
+
+
+def spmm_nofma(ptr, idx, val, vin):
+    ptr, idx, val = _csr(ptr, idx, val)
+    vin = np.ascontiguousarray(vin, dtype=np.float32)
+    num_v = ptr.size - 1
+    out = np.empty((num_v, vin.shape[1]), dtype=np.float32)
+    lib().oracle_spmm_nofma(_p(ptr), _p(idx), _p(val), _p(vin), _p(out), num_v, vin.shape[1])
+    return out
+
+
+def spmm_omp(ptr, idx, val, vin, out=None, row_begin=0, row_end=-1, feat=None, ldb=None):
+    """Same arithmetic, OpenMP over rows, vectorised over columns (the cpu_baseline 'port')."""
+    ptr, idx, val = _csr(ptr, idx, val)
+    assert vin.dtype == np.float32 and vin.flags.c_contiguous
+    num_v = ptr.size - 1
+    feat = vin.shape[1] if feat is None else feat
+    ldb = vin.shape[1] if ldb is None else ldb
+    if out is None:
+        out = np.empty((num_v, feat), dtype=np.float32)
+    lib().oracle_spmm_omp(_p(ptr), _p(idx), _p(val), _p(vin), ldb, _p(out), out.shape[1], num_v, feat, row_begin, row_end)
+    return out
+
+
+def spmm_f64(ptr, idx, val, vin, with_abs=True):
+    ptr, idx, val = _csr(ptr, idx, val)
+    vin = np.ascontiguousarray(vin, dtype=np.float32)
+    num_v = ptr.size - 1
+    out = np.empty((num_v, vin.shape[1]), dtype=np.float64)
+    ab = np.empty_like(out) if with_abs else None
+    lib().oracle_spmm_f64(_p(ptr), _p(idx), _p(val), _p(vin), _p(out), _p(ab) if with_abs else None, num_v, vin.shape[1])
+    return out, ab
+
+
+def spmm_chunked(ptr, idx, val, vin, threshold, chunk):
+    """What the device computes for rows longer than `threshold`: per-chunk fma chains
+    (each exactly the oracle on the chunk) summed left to right in chunk order with fp32
+    adds.  Rows at or below the threshold are the plain oracle.  Built FROM the oracle: the
+    chunks are presented to oracle_spmm_omp as rows of an expanded CSR."""
+    ptr, idx, val = _csr(ptr, idx, val)
+    vin = np.ascontiguousarray(vin, dtype=np.float32)
+    out = spmm_omp(ptr, idx, val, vin)
+    deg = np.diff(ptr)
+    for r in np.nonzero(deg > threshold)[0]:
+        b, e = int(ptr[r]), int(ptr[r + 1])
+        cuts = list(range(b, e, chunk)) + [e]
+        sub_ptr = np.asarray(cuts, dtype=np.int32) - b
+        parts = spmm_omp(sub_ptr, idx[b:e], val[b:e], vin)
+        acc = parts[0].copy()
+        for i in range(1, parts.shape[0]):
+            acc = (acc + parts[i]).astype(np.float32)
+        out[r] = acc
+    return out
+
+
+def valid_float(y, y2):
+    y = np.ascontiguousarray(y, dtype=np.float32).ravel()
+    y2 = np.ascontiguousarray(y2, dtype=np.float32).ravel()
+    return int(lib().oracle_valid_float(_p(y), _p(y2), y.size))
+
+
+def valid_int(y, y2):
+    y = np.ascontiguousarray(y, dtype=np.int32).ravel()
+    y2 = np.ascontiguousarray(y2, dtype=np.int32).ravel()
+    return int(lib().oracle_valid_int(_p(y), _p(y2), y.size))
+
+
+def validation_passes(bad, num_v, feat):
+    return bool(lib().oracle_validation_passes(int(bad), int(num_v), int(feat)))
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def fnv1a64(a):
+    a = np.ascontiguousarray(a)
+    return int(lib().oracle_fnv1a64(_p(a), a.nbytes))
+
+
+# ---- the reference's own kernels on the GPU (oracle/_ref) ---------------------------------
+def ref_available():
+    return os.path.exists(REF_LIB)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_LIB)
+        P = C.c_void_p
+        L.ref_spmm_ref_run.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
+        L.ref_spmm_ref_run.restype = C.c_int
+        L.ref_spmm_opt_preprocess.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int)]
+        L.ref_spmm_opt_preprocess.restype = C.c_int
+        L.ref_spmm_opt_run.argtypes = [P, C.c_int, P, P, P, P, C.c_int, P]
+        L.ref_spmm_opt_run.restype = C.c_int
+        L.ref_free.argtypes = [P]
+        L.ref_free.restype = C.c_int
+        L.ref_valid_float.argtypes = [P, P, C.c_int, C.POINTER(C.c_int)]
+        L.ref_valid_float.restype = C.c_int
+        L.ref_valid_int.argtypes = [P, P, C.c_int, C.POINTER(C.c_int)]
+        L.ref_valid_int.restype = C.c_int
+        _ref = L
+    return _ref
+
+
+def ref_kernel_run(d_ptr, d_idx, d_val, d_vin, d_vout, num_v, feat, stream=0):
+    """spmm_kernel_ref itself (reference source, hipcc) on torch device tensors."""
+    rc = ref_lib().ref_spmm_ref_run(d_ptr.data_ptr(), d_idx.data_ptr(), d_val.data_ptr(), d_vin.data_ptr(),
+                                    d_vout.data_ptr(), int(num_v), int(feat), stream)
+    if rc:
+        raise RuntimeError(f"ref_spmm_ref_run -> hip error {rc}")
+
+
+class RefOpt:
+    """The student's SpmmOptKernel itself (reference source, hipcc): preprocess + run."""
+
+    def __init__(self, d_ptr, d_idx, d_val, num_v, feat):
+        self.d_idx, self.d_val, self.feat, self.num_v = d_idx, d_val, int(feat), int(num_v)
+        self.tasks = C.c_void_p(None)
+        n = C.c_int(0)
+        rc = ref_lib().ref_spmm_opt_preprocess(d_ptr.data_ptr(), self.num_v, C.byref(self.tasks), C.byref(n))
+        if rc:
+            raise RuntimeError(f"ref_spmm_opt_preprocess -> {rc}")
+        self.n_tasks = n.value
+
+    def run(self, d_vin, d_vout, stream=0):
+        rc = ref_lib().ref_spmm_opt_run(self.tasks, self.n_tasks, self.d_idx.data_ptr(), self.d_val.data_ptr(),
+                                        d_vin.data_ptr(), d_vout.data_ptr(), self.feat, stream)
+        if rc:
+            raise RuntimeError(f"ref_spmm_opt_run -> {rc}")
+
+    def __del__(self):
+        if getattr(self, "tasks", None) is not None and self.tasks.value:
+            ref_lib().ref_free(self.tasks)
+            self.tasks = C.c_void_p(None)
+
+
+def ref_valid(d_y, d_y2, num):
+    import torch
+
+    bad = C.c_int(-1)
+    if d_y.dtype == torch.float32:
+        rc = ref_lib().ref_valid_float(d_y.data_ptr(), d_y2.data_ptr(), int(num), C.byref(bad))
+    else:
+        rc = ref_lib().ref_valid_int(d_y.data_ptr(), d_y2.data_ptr(), int(num), C.byref(bad))
+    if rc:
+        raise RuntimeError(f"ref_valid -> {rc}")
+    return bad.value

@@ -1,0 +1,182 @@
+/*
+ * oracle/spmm_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's CSR SpMM arithmetic and of its own
+ * comparison rules.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product path (hpc_amd/,
+ * include/, hpc_amd/csrc/) never links, imports or calls it.
+ *
+ * Reference followed (paths relative to /root/reference/PA4/workspace):
+ *   src/spmm_ref.cu:3-17     spmm_kernel_ref  -- the arithmetic definition
+ *   src/spmm_ref.cu:20-30    launch geometry (one thread per row)
+ *   include/util.h:120-129   struct CSR {num_v, num_e, ptr, idx, val}
+ *   src/spmm_cusparse.cu:6-15  0-based indices, row-major dense, ld = N
+ *   src/valid.cu:3-20        validate_float / validate_int comparison rules
+ *   test/test_spmm.cu:43     pass criterion  bad < M*N/10000 + 1
+ *
+ * Pinning: the reference holds no golden vectors for this path (SURVEY.md
+ * section 8c).  The restatement is pinned bit-for-bit against the reference
+ * kernel itself -- spmm_ref.cu:3-17 compiled by hipcc from the reference tree
+ * in place (oracle/Makefile target _ref) and run on an MI355X -- through the
+ * fixtures under tests/golden/ (made by tests/golden/make_golden.py) and,
+ * on the GPU box, live in tests/test_ref_kernel_gpu.py.
+ *
+ * Contraction mode is part of the definition: the reference builds with
+ * nvcc -O3 --use_fast_math (CMakeLists.txt:46), i.e. fmad on, so
+ * `result += vin[..] * val[i]` is ONE fused multiply-add per term.  The
+ * canonical oracle therefore uses explicit fmaf, i ascending, accumulator
+ * starting at +0.0f.  A non-fused variant exists only to document the gap.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* spmm_ref.cu:3-17, one "thread" (row) at a time, loop order kept:
+ * outer j over the N dense columns, inner i over the row's nonzeros.
+ * Index arithmetic is widened to 64 bit (the reference's `idx[i]*INFEATURE+j`
+ * is int and overflows past 2^31 elements -- SURVEY.md H5); values identical
+ * wherever the reference is defined. */
+void oracle_spmm_ref(const int32_t *ptr, const int32_t *idx, const float *val,
+                     const float *vin, float *vout, int32_t num_v,
+                     int32_t feat)
+{
+    for (int32_t tid = 0; tid < num_v; ++tid) {
+        const int32_t begin = ptr[tid], end = ptr[tid + 1];
+        for (int32_t j = 0; j < feat; ++j) {
+            float result = 0.0f;
+            for (int32_t i = begin; i < end; ++i)
+                result = fmaf(vin[(int64_t)idx[i] * feat + j], val[i], result);
+            vout[(int64_t)tid * feat + j] = result;
+        }
+    }
+}
+
+/* Same per-element arithmetic (per (row, j): fmaf chain, i ascending) with
+ * the loops interchanged so the inner loop runs over contiguous columns and
+ * vectorises, and OpenMP over rows.  Bitwise equal to oracle_spmm_ref by
+ * construction (each output element sees the same operands in the same
+ * order); tests assert it.  This is the cpu_baseline ("port") timed by
+ * bench.py on the GPU box's host cores.
+ * ldb/ldc are row pitches in floats (reference: both = feat). */
+void oracle_spmm_omp(const int32_t *ptr, const int32_t *idx, const float *val,
+                     const float *vin, int64_t ldb, float *vout, int64_t ldc,
+                     int32_t num_v, int32_t feat, int32_t row_begin,
+                     int32_t row_end)
+{
+    if (row_begin < 0) row_begin = 0;
+    if (row_end > num_v || row_end < 0) row_end = num_v;
+#pragma omp parallel
+    {
+        float *acc = (float *)malloc(sizeof(float) * (size_t)(feat > 0 ? feat : 1));
+#pragma omp for schedule(dynamic, 64)
+        for (int32_t r = row_begin; r < row_end; ++r) {
+            for (int32_t j = 0; j < feat; ++j) acc[j] = 0.0f;
+            const int32_t begin = ptr[r], end = ptr[r + 1];
+            for (int32_t i = begin; i < end; ++i) {
+                const float a = val[i];
+                const float *brow = vin + (int64_t)idx[i] * ldb;
+                for (int32_t j = 0; j < feat; ++j)
+                    acc[j] = fmaf(brow[j], a, acc[j]);
+            }
+            memcpy(vout + (int64_t)r * ldc, acc, sizeof(float) * (size_t)feat);
+        }
+        free(acc);
+    }
+}
+
+/* Documentation variant: separate multiply and add (what a build WITHOUT fmad
+ * would give).  Not the oracle; used by one test that records how far the
+ * two contraction modes sit apart. */
+void oracle_spmm_nofma(const int32_t *ptr, const int32_t *idx, const float *val,
+                       const float *vin, float *vout, int32_t num_v,
+                       int32_t feat)
+{
+    for (int32_t tid = 0; tid < num_v; ++tid) {
+        const int32_t begin = ptr[tid], end = ptr[tid + 1];
+        for (int32_t j = 0; j < feat; ++j) {
+            volatile float result = 0.0f;
+            for (int32_t i = begin; i < end; ++i) {
+                volatile float p = vin[(int64_t)idx[i] * feat + j] * val[i];
+                result = result + p;
+            }
+            vout[(int64_t)tid * feat + j] = result;
+        }
+    }
+}
+
+/* fp64 value and fp64 sum of |a*b| per output element: the yardstick for the
+ * order-changing device paths (split long rows, block/MFMA path):
+ *   |c - c_oracle| <= tol * sum_k |a_k b_k|      (SURVEY.md H1, 8d). */
+void oracle_spmm_f64(const int32_t *ptr, const int32_t *idx, const float *val,
+                     const float *vin, double *vout, double *vabs,
+                     int32_t num_v, int32_t feat)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int32_t r = 0; r < num_v; ++r) {
+        double *o = vout + (int64_t)r * feat;
+        double *s = vabs ? vabs + (int64_t)r * feat : 0;
+        for (int32_t j = 0; j < feat; ++j) { o[j] = 0.0; if (s) s[j] = 0.0; }
+        for (int32_t i = ptr[r]; i < ptr[r + 1]; ++i) {
+            const double a = val[i];
+            const float *brow = vin + (int64_t)idx[i] * feat;
+            for (int32_t j = 0; j < feat; ++j) {
+                const double p = a * (double)brow[j];
+                o[j] += p;
+                if (s) s[j] += fabs(p);
+            }
+        }
+    }
+}
+
+/* valid.cu:3-11 + 36-51.  The reference calls valid(y = opt output,
+ * y2 = SpMMRef output) (test_spmm.cu:43) and the kernel's parameters are
+ * (ref = y, ans = y2): the quotient is taken against the FIRST argument.
+ * `abs(float)` is the float overload in device code; `> 1e-2` compares
+ * against a double constant, so the float quotient is promoted.  0/0 gives
+ * NaN (not counted), x/0 gives inf (counted) -- SURVEY.md section 4. */
+int64_t oracle_valid_float(const float *y, const float *y2, int64_t num)
+{
+    int64_t diffnum = 0;
+    for (int64_t tid = 0; tid < num; ++tid) {
+        const float q = fabsf((y[tid] - y2[tid]) / y[tid]);
+        if ((double)q > 1e-2) ++diffnum;
+    }
+    return diffnum;
+}
+
+/* valid.cu:13-20 + 22-34 */
+int64_t oracle_valid_int(const int32_t *y, const int32_t *y2, int64_t num)
+{
+    int64_t diffnum = 0;
+    for (int64_t tid = 0; tid < num; ++tid)
+        if (y[tid] != y2[tid]) ++diffnum;
+    return diffnum;
+}
+
+/* test_spmm.cu:43: ASSERT_LT(valid(...), kNumV * kLen / 10000 + 1) */
+int oracle_validation_passes(int64_t bad, int64_t num_v, int64_t feat)
+{
+    return bad < num_v * feat / 10000 + 1;
+}
+
+int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* FNV-1a 64 over raw bytes: checksum-of-outputs for large cases. */
+uint64_t oracle_fnv1a64(const void *data, int64_t nbytes)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    uint64_t h = 1469598103934665603ULL;
+    for (int64_t i = 0; i < nbytes; ++i) { h ^= p[i]; h *= 1099511628211ULL; }
+    return h;
+}

@@ -1,0 +1,77 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # -m gpu on a box without a GPU must fail loudly, not skip: a green run has to mean the HIP path ran.
+    # Without -m gpu (the CPU container) gpu tests are deselected by the driver's -m "not gpu".
+    pass
+
+
+@pytest.fixture(scope="session")
+def device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: gpu-marked tests must run on the MI355X box")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+
+    o.lib()
+    return o
+
+
+def to_dev(device, *arrays):
+    import torch
+
+    out = []
+    for a in arrays:
+        out.append(torch.from_numpy(np.ascontiguousarray(a)).to(device))
+    return out
+
+
+def run_spmm(device, ptr, idx, vals, B, options=None, poison=True, num_cols=None, N=None):
+    """CSR + dense B (numpy) -> C (numpy) through the product path (C ABI), NaN-poisoned output."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M = ptr.size - 1
+    N = B.shape[1] if N is None else N
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr.astype(np.int32), idx.astype(np.int32), vals.astype(np.float32), B.astype(np.float32))
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device) if poison else torch.zeros((M, N), dtype=torch.float32, device=device)
+    g = CSR(M, idx.size, d_ptr, d_idx, d_val)
+    op = SpMMOpt(g, N, num_cols=B.shape[0] if num_cols is None else num_cols)
+    for k, v in (options or {}).items():
+        op.set_option(k, v)
+    op.preprocess(d_B, d_C)
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    return d_C.cpu().numpy(), op
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

@@ -1,0 +1,75 @@
+"""The C-ABI library loads on a box without a GPU and exports every symbol include/mi_spmm.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mi_spmm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_spmm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = _declared()
+    for must in ("mi_spmm_create", "mi_spmm_preprocess", "mi_spmm_run", "mi_spmm_destroy", "mi_spmm_strerror",
+                 "mi_spmm_valid_float", "mi_spmm_valid_int"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from hpc_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in include/mi_spmm.h but not exported"
+
+
+def test_binding_table_covers_header():
+    from hpc_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.mi_spmm_abi_version() == 1
+    assert b"gfx950" in lib.mi_spmm_build_info()
+    assert b"ok" == lib.mi_spmm_strerror(0)
+    assert b"CSR" in lib.mi_spmm_strerror(-4)
+
+
+def test_argument_checks_without_a_gpu():
+    """Pure host-side validation paths (no device call is reached)."""
+    from hpc_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p(None)
+    assert lib.mi_spmm_create(ctypes.byref(h), None, None, None, 4, 4, 0, 8) == -1          # NULL row_ptr
+    assert lib.mi_spmm_create(None, None, None, None, 4, 4, 0, 8) == -1
+    dummy = (ctypes.c_int32 * 5)()
+    assert lib.mi_spmm_create(ctypes.byref(h), dummy, None, None, -1, 4, 0, 8) == -1         # negative size
+    assert lib.mi_spmm_create(ctypes.byref(h), dummy, None, None, 4, 4, 3, 8) == -1          # nnz>0, NULL idx
+    assert lib.mi_spmm_create(ctypes.byref(h), dummy, None, None, 4, 4, 0, 8) == 0
+    assert lib.mi_spmm_run(h, None, None, None) == -3                                         # run before preprocess
+    assert lib.mi_spmm_set_option(h, b"unroll", 3) == -1
+    assert lib.mi_spmm_set_option(h, b"no_such_key", 1) == -5
+    assert lib.mi_spmm_set_option(h, b"unroll", 16) == 0
+    v = ctypes.c_int64(0)
+    assert lib.mi_spmm_get_option(h, b"unroll", ctypes.byref(v)) == 0 and v.value == 16
+    assert lib.mi_spmm_destroy(h) == 0
+    assert lib.mi_spmm_destroy(None) == 0
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under hpc_amd/, include/ or bench's product leg may import or link oracle/."""
+    for base in ("hpc_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dirpath.split(os.sep):
+                continue
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    for line in text.splitlines():
+                        s = line.strip()
+                        if s.startswith(("#include", "import ", "from ")) or "CDLL" in s or "-l" in s:
+                            assert "oracle" not in s, f"{dirpath}/{f}: {s}"

@@ -1,0 +1,107 @@
+"""CPU tests of the oracle (test infrastructure): internal consistency, the reference's own
+comparison rules (valid.cu), and the golden fixtures made by the reference kernel on MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from hpc_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_ref_and_omp_forms_are_bitwise_equal(oracle):
+    ptr, idx, vals, B, _ = synth.config("C0")
+    a = oracle.spmm_ref(ptr, idx, vals, B)
+    b = oracle.spmm_omp(ptr, idx, vals, B)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_hand_checkable_case(oracle):
+    # 3x3: row0 = {(0,2.0),(2,-1.0)}, row1 empty, row2 = {(1,0.5)}
+    ptr = np.array([0, 2, 2, 3], np.int32)
+    idx = np.array([0, 2, 1], np.int32)
+    val = np.array([2.0, -1.0, 0.5], np.float32)
+    B = np.array([[1, 2], [3, 4], [5, 6]], np.float32)
+    C = oracle.spmm_ref(ptr, idx, val, B)
+    assert np.array_equal(C, np.array([[2 * 1 - 5, 2 * 2 - 6], [0, 0], [1.5, 2.0]], np.float32))
+
+
+def test_empty_rows_write_zero_and_duplicates_accumulate(oracle):
+    ptr = np.array([0, 0, 3, 3], np.int32)
+    idx = np.array([1, 1, 0], np.int32)           # duplicate column in a row: both terms count
+    val = np.array([1.0, 2.0, 4.0], np.float32)
+    B = np.arange(6, dtype=np.float32).reshape(3, 2)
+    C = oracle.spmm_ref(ptr, idx, val, B)
+    assert np.array_equal(C[0], [0, 0]) and np.array_equal(C[2], [0, 0])
+    assert np.array_equal(C[1], 3 * B[1] + 4 * B[0])
+
+
+def test_fma_matters(oracle):
+    """the fused and unfused builds of the same loop differ in about half the
+    elements -- the oracle pins contraction to fma (nvcc --use_fast_math => fmad)."""
+    ptr, idx, vals, B, _ = synth.config("C0")
+    a = oracle.spmm_ref(ptr, idx, vals, B)
+    c = oracle.spmm_nofma(ptr, idx, vals, B)
+    assert (a != c).sum() > a.size // 4
+    assert np.abs(a - c).max() < 1e-6
+
+
+def test_against_fp64_and_scipy(oracle):
+    import scipy.sparse as sp
+
+    ptr, idx, vals, B, meta = synth.config("C0")
+    f64, sabs = oracle.spmm_f64(ptr, idx, vals, B)
+    A = sp.csr_matrix((vals.astype(np.float64), idx, ptr), shape=(meta["M"], meta["K"]))
+    assert np.abs(A @ B.astype(np.float64) - f64).max() < 1e-12
+    a = oracle.spmm_ref(ptr, idx, vals, B)
+    err = np.abs(a - f64)
+    assert (err <= 1e-6 * sabs + 1e-30).all()
+
+
+def test_valid_float_rules(oracle):
+    # valid.cu:6: |(y - y2)/y| > 1e-2, quotient against the FIRST argument; 0/0 not counted, x/0 counted
+    y = np.array([1.0, 1.0, 0.0, 0.0, 100.0, -2.0], np.float32)
+    y2 = np.array([1.0, 1.02, 0.0, 1e-9, 100.9, -2.03], np.float32)
+    #             ok    bad   nan->ok  inf->bad  ok(0.9%)  bad(1.5%)
+    assert oracle.valid_float(y, y2) == 3
+    assert oracle.valid_int(np.array([1, 2, 3]), np.array([1, 5, 3])) == 1
+    # test_spmm.cu:43  bad < M*N/10000 + 1
+    assert oracle.validation_passes(0, 10, 10)
+    assert not oracle.validation_passes(1, 10, 10)
+    assert oracle.validation_passes(3, 1024, 32)
+    assert not oracle.validation_passes(4, 1024, 32)
+
+
+def test_chunked_order_helper_matches_oracle_below_threshold(oracle):
+    ptr, idx, vals, B, _ = synth.config("C0")
+    a = oracle.spmm_omp(ptr, idx, vals, B)
+    b = oracle.spmm_chunked(ptr, idx, vals, B, threshold=1 << 30, chunk=256)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    c = oracle.spmm_chunked(ptr, idx, vals, B, threshold=8, chunk=8)
+    f64, sabs = oracle.spmm_f64(ptr, idx, vals, B)
+    assert (np.abs(c - f64) <= 1e-6 * sabs + 1e-30).all()
+
+
+def _golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def test_golden_fixtures_exist():
+    assert _golden_files(), "tests/golden/*.npz missing: run tests/golden/make_golden.py on the GPU box"
+
+
+@pytest.mark.parametrize("path", _golden_files(), ids=lambda p: os.path.basename(p))
+def test_oracle_reproduces_reference_kernel_goldens(oracle, path):
+    """The fixtures hold outputs of the REFERENCE kernel (spmm_ref.cu:3-17 compiled by hipcc,
+    run on an MI355X).  The CPU restatement must reproduce them bit for bit."""
+    z = np.load(path)
+    out = oracle.spmm_ref(z["row_ptr"], z["col_idx"], z["vals"], z["B"])
+    exp = z["C_ref_kernel"]
+    assert out.shape == exp.shape
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), (
+        f"{(out.view(np.uint32) != exp.view(np.uint32)).sum()} of {out.size} elements differ"
+    )
+    out2 = oracle.spmm_omp(z["row_ptr"], z["col_idx"], z["vals"], z["B"])
+    assert np.array_equal(out2.view(np.uint32), exp.view(np.uint32))

@@ -1,0 +1,229 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle.
+
+Bar (BASELINE.json north_star): bit-exact wherever the summation order is the reference's
+(every row at or below the split threshold); rows split into chunks are bit-exact against the
+oracle evaluated in the same chunk order and within 1e-5 * sum|a_k b_k| of the plain oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits, run_spmm, to_dev
+from hpc_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL_SPLIT = 1e-5  # |c - c_oracle| <= TOL_SPLIT * sum_k |a_k b_k|  (order-changing path only)
+
+
+def _rand_case(M, K, N, deg_lo, deg_hi, seed):
+    ptr, idx = synth.csr_uniform(M, deg_lo, deg_hi, K=K, seed=seed)
+    return ptr, idx, synth.normal_f32(idx.size, seed + 1), synth.normal_f32(K * N, seed + 2).reshape(K, N)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=lambda p: os.path.basename(p))
+def test_goldens_bitwise(device, path):
+    z = np.load(path)
+    C, _ = run_spmm(device, z["row_ptr"], z["col_idx"], z["vals"], z["B"], options={"long_row_threshold": 1 << 30})
+    assert np.array_equal(bits(C), bits(z["C_ref_kernel"]))
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 64, 100, 128, 132, 256, 260, 512, 1024])
+def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
+    M, K = 777, 513
+    ptr, idx, vals, B = _rand_case(M, K, N, 0, 70, seed=100 + N)
+    C, op = run_spmm(device, ptr, idx, vals, B)
+    ref = oracle.spmm_omp(ptr, idx, vals, B)
+    assert not np.isnan(C).any(), "output not fully overwritten"
+    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).sum()} elements differ"
+    assert op.get_option("vector_width") == (4 if N % 4 == 0 else 1)
+
+
+@pytest.mark.parametrize("unroll", [4, 8, 16])
+@pytest.mark.parametrize("pol", [0, 1, 2, 3])
+@pytest.mark.parametrize("N", [32, 128, 256])
+def test_bitwise_over_tuning_knobs(device, oracle, unroll, pol, N):
+    ptr, idx, vals, B = _rand_case(2000, 2000, N, 0, 90, seed=7)
+    ref = oracle.spmm_omp(ptr, idx, vals, B)
+    for rpb, xcd in ((0, 1), (16, 0), (1000, 1)):
+        C, _ = run_spmm(device, ptr, idx, vals, B, options={
+            "unroll": unroll, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd})
+        assert np.array_equal(bits(C), bits(ref))
+
+
+def test_edge_shapes(device, oracle):
+    # M = 1; all rows empty; a single nonzero; K != M; nnz = 0
+    for (M, K, N, lo, hi, seed) in [(1, 1, 4, 1, 1, 1), (5, 9, 8, 0, 0, 2), (1, 300, 128, 200, 200, 3), (300, 7, 16, 0, 7, 4), (64, 64, 128, 64, 64, 5)]:
+        ptr, idx, vals, B = _rand_case(M, K, N, lo, hi, seed)
+        C, _ = run_spmm(device, ptr, idx, vals, B)
+        assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (M, K, N)
+
+
+def test_empty_matrix_and_zero_width(device):
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    d_ptr = torch.zeros(1, dtype=torch.int32, device=device)
+    d_idx = torch.zeros(0, dtype=torch.int32, device=device)
+    d_val = torch.zeros(0, dtype=torch.float32, device=device)
+    d_B = torch.zeros(0, dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(0, 0, d_ptr, d_idx, d_val), 16)
+    op.preprocess(d_B, d_B)
+    op.run(d_B, d_B)
+    torch.cuda.synchronize()
+
+
+def test_overwrite_and_idempotent(device, oracle):
+    """run() leaves vout = A*vin whatever vout held (spmm_ref.cu:15, cuSPARSE beta=0) and may be
+    called back to back (util.h:143-149) -- unlike the student kernel, which accumulates (H7)."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx, vals, B = _rand_case(3000, 3000, 64, 0, 600, seed=9)   # includes split rows (> 512)
+    ptr[-1] == idx.size
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((3000, 64), 1e30, dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(3000, idx.size, d_ptr, d_idx, d_val), 64)
+    op.preprocess(d_B, d_C)
+    assert op.get_option("n_long_rows") > 0
+    op.run(d_B, d_C)
+    first = d_C.clone()
+    for _ in range(3):
+        op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert torch.equal(first.view(torch.int32), d_C.view(torch.int32))
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+
+
+@pytest.mark.parametrize("thr,chunk", [(8, 8), (16, 5), (64, 64), (100, 256)])
+@pytest.mark.parametrize("N", [5, 32, 128, 256])
+def test_split_rows_chunk_order_and_tolerance(device, oracle, thr, chunk, N):
+    ptr, idx, vals, B = _rand_case(400, 900, N, 0, 300, seed=31)
+    C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": thr, "long_row_chunk": chunk})
+    assert op.get_option("n_long_rows") == int((np.diff(ptr) > thr).sum())
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, thr, chunk)
+    assert np.array_equal(bits(C), bits(exp)), "device chunk order differs from the documented one"
+    plain = oracle.spmm_omp(ptr, idx, vals, B)
+    _, sabs = oracle.spmm_f64(ptr, idx, vals, B)
+    assert (np.abs(C.astype(np.float64) - plain) <= TOL_SPLIT * sabs + 1e-30).all()
+    short = np.diff(ptr) <= thr
+    assert np.array_equal(bits(C[short]), bits(plain[short])), "rows below the threshold must stay bit-exact"
+
+
+def test_power_law_rows(device, oracle):
+    ptr, idx = synth.csr_powerlaw(20000, 32.0, 4096, seed=5)
+    vals = synth.normal_f32(idx.size, 6)
+    B = synth.normal_f32(20000 * 128, 7).reshape(20000, 128)
+    C, op = run_spmm(device, ptr, idx, vals, B)
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+    assert np.array_equal(bits(C), bits(exp))
+    C2, _ = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 1 << 30})
+    assert np.array_equal(bits(C2), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+
+
+def test_block_dense_rows(device, oracle):
+    ptr, idx = synth.csr_block_dense_fast(4096)
+    vals = synth.normal_f32(idx.size, 6)
+    B = synth.normal_f32(4096 * 256, 7).reshape(4096, 256)
+    C, _ = run_spmm(device, ptr, idx, vals, B)
+    assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+
+
+def test_column_slices_with_pitches(device, oracle):
+    """run_ld: a shard reads its column block of a wider B and writes its block of a wider C."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M, N, G = 500, 256, 4
+    ptr, idx, vals, B = _rand_case(M, M, N, 0, 50, seed=41)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    n_loc = N // G
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
+    op.preprocess(d_B, d_C)
+    for g in range(G):
+        op.run_ld(d_B.view(-1)[g * n_loc:], N, d_C.view(-1)[g * n_loc:], N)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+
+
+def test_unpack_gathered(device):
+    import torch
+    from hpc_amd.spmm import unpack_gathered
+
+    for rows, G, n_loc in [(37, 4, 32), (5, 3, 6), (64, 8, 128)]:
+        st = torch.randn(G, rows, n_loc, device=device)
+        C = torch.full((rows, G * n_loc), float("nan"), device=device)
+        unpack_gathered(st, C, rows, G, n_loc, G * n_loc)
+        torch.cuda.synchronize()
+        assert torch.equal(C, st.permute(1, 0, 2).reshape(rows, G * n_loc))
+
+
+def test_validator_matches_reference_rules(device, oracle):
+    import torch
+    from hpc_amd import valid
+
+    g = np.random.Generator(np.random.Philox(key=[3, 3]))
+    y = g.standard_normal(100000).astype(np.float32)
+    y2 = (y * (1 + g.standard_normal(100000) * 0.008)).astype(np.float32)
+    y[:50] = 0.0
+    y2[:25] = 0.0       # 0/0 -> NaN, not counted ; x/0 -> inf, counted
+    d_y, d_y2 = to_dev(device, y, y2)
+    assert valid(d_y, d_y2, y.size) == oracle.valid_float(y, y2)
+    a = g.integers(0, 5, 10000).astype(np.int32)
+    b = g.integers(0, 5, 10000).astype(np.int32)
+    d_a, d_b = to_dev(device, a, b)
+    assert valid(d_a, d_b, a.size) == oracle.valid_int(a, b) == int((a != b).sum())
+    if oracle.ref_available():   # the reference's own validator kernels, compiled by hipcc
+        assert oracle.ref_valid(d_y, d_y2, y.size) == oracle.valid_float(y, y2)
+        assert oracle.ref_valid(d_a, d_b, a.size) == oracle.valid_int(a, b)
+
+
+def test_malformed_csr_is_rejected_not_faulted(device):
+    import torch
+    from hpc_amd import CSR, SpMMOpt, MiSpmmError
+
+    M, N = 16, 8
+    B = torch.zeros(M, N, device=device)
+    Cc = torch.zeros(M, N, device=device)
+    val = torch.ones(4, device=device)
+    bad_cases = {
+        "col out of range": (np.array([0, 1, 2, 3, 4] + [4] * 12, np.int32), np.array([0, 1, 2, 99], np.int32)),
+        "negative col": (np.array([0, 1, 2, 3, 4] + [4] * 12, np.int32), np.array([0, -1, 2, 3], np.int32)),
+        "non-monotone ptr": (np.array([0, 3, 2, 3, 4] + [4] * 12, np.int32), np.array([0, 1, 2, 3], np.int32)),
+        "ptr[M] != nnz": (np.array([0, 1, 2, 3, 3] + [3] * 12, np.int32), np.array([0, 1, 2, 3], np.int32)),
+    }
+    for why, (ptr, idx) in bad_cases.items():
+        d_ptr, d_idx = to_dev(device, ptr, idx)
+        op = SpMMOpt(CSR(M, 4, d_ptr, d_idx, val), N)
+        with pytest.raises(MiSpmmError) as e:
+            op.preprocess(B, Cc)
+        assert e.value.code == -4, why
+        with pytest.raises(MiSpmmError):
+            op.run(B, Cc)   # never prepared -> ESTATE, no launch
+
+
+def test_reference_kernel_agrees_with_oracle_live(device, oracle):
+    """Live pinning on the GPU box: the reference's spmm_kernel_ref (hipcc-compiled from the
+    reference tree) == CPU restatement == our kernel, bit for bit, on a mid-size random case."""
+    import torch
+
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref/libspmm_ref_gfx950.so did not travel to the GPU box")
+    M, N = 20000, 64
+    ptr, idx, vals, B = _rand_case(M, M, N, 0, 64, seed=77)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_C, M, N)
+    torch.cuda.synchronize()
+    ref_gpu = d_C.cpu().numpy()
+    cpu = oracle.spmm_omp(ptr, idx, vals, B)
+    assert np.array_equal(bits(ref_gpu), bits(cpu))
+    ours, _ = run_spmm(device, ptr, idx, vals, B)
+    assert np.array_equal(bits(ours), bits(ref_gpu))
+    # and the reference's own acceptance test (test_spmm.cu:43) passes with zero bad elements
+    from hpc_amd import valid
+    d_o = torch.from_numpy(ours).to(device)
+    assert valid(d_o, d_C, M * N) == 0
