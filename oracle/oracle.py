@@ -1,7 +1,7 @@
 """ctypes front end of the oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
-this module.  hpc_amd/ never does (tests/test_no_oracle_in_product.py checks).
+this module.  hpc_amd/ never does (tests/test_abi_symbols.py::test_product_never_touches_the_oracle checks).
 
   liboracle.so                      CPU restatement (oracle/spmm_oracle.c)
   _ref/libspmm_ref_gfx950.so        the reference's own kernels compiled by hipcc from
@@ -29,9 +29,39 @@ def build(ref=True):
         subprocess.check_call(["make", "-s", "-C", _HERE, "_ref"])
 
 
+def available_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    env = os.environ.get("ORACLE_THREADS")
+    if env:
+        n = max(1, int(env))
+    return n
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         if not os.path.exists(LIB):
             build(ref=False)
         L = C.CDLL(LIB)
@@ -51,6 +81,9 @@ def lib():
         L.oracle_validation_passes.argtypes = [C.c_int64, C.c_int64, C.c_int64]
         L.oracle_validation_passes.restype = C.c_int
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_threads.restype = None
+        L.oracle_set_threads(min(available_cores(), 64))
         L.oracle_fnv1a64.argtypes = [P, C.c_int64]
         L.oracle_fnv1a64.restype = C.c_uint64
         _lib = L

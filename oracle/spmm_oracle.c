@@ -19,7 +19,7 @@
  * kernel itself -- spmm_ref.cu:3-17 compiled by hipcc from the reference tree
  * in place (oracle/Makefile target _ref) and run on an MI355X -- through the
  * fixtures under tests/golden/ (made by tests/golden/make_golden.py) and,
- * on the GPU box, live in tests/test_ref_kernel_gpu.py.
+ * on the GPU box, live in tests/test_parity_gpu.py (test_reference_kernel_agrees_with_oracle_live).
  *
  * Contraction mode is part of the definition: the reference builds with
  * nvcc -O3 --use_fast_math (CMakeLists.txt:46), i.e. fmad on, so
@@ -69,7 +69,8 @@ void oracle_spmm_omp(const int32_t *ptr, const int32_t *idx, const float *val,
 {
     if (row_begin < 0) row_begin = 0;
     if (row_end > num_v || row_end < 0) row_end = num_v;
-#pragma omp parallel
+    const int go_parallel = (row_end - row_begin) >= 512;
+#pragma omp parallel if (go_parallel)
     {
         float *acc = (float *)malloc(sizeof(float) * (size_t)(feat > 0 ? feat : 1));
 #pragma omp for schedule(dynamic, 64)
@@ -115,7 +116,7 @@ void oracle_spmm_f64(const int32_t *ptr, const int32_t *idx, const float *val,
                      const float *vin, double *vout, double *vabs,
                      int32_t num_v, int32_t feat)
 {
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) if (num_v >= 512)
     for (int32_t r = 0; r < num_v; ++r) {
         double *o = vout + (int64_t)r * feat;
         double *s = vabs ? vabs + (int64_t)r * feat : 0;
@@ -161,6 +162,17 @@ int64_t oracle_valid_int(const int32_t *y, const int32_t *y2, int64_t num)
 int oracle_validation_passes(int64_t bad, int64_t num_v, int64_t feat)
 {
     return bad < num_v * feat / 10000 + 1;
+}
+
+/* Worker-thread control: a GPU box exposes 256 host CPUs but grants a share of
+ * them; spinning on more threads than that makes small calls crawl. */
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int oracle_num_threads(void)
