@@ -41,6 +41,11 @@ struct mi_spmm_handle {
     int32_t max_row_nnz;
     double preprocess_us;
     int32_t last_lpr, last_v, last_launches;
+    // block (MFMA) path
+    int64_t block_min_len;
+    uint8_t *d_blk_flag;
+    int32_t *d_blk_groups;
+    int32_t n_blk_groups;
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
@@ -52,6 +57,11 @@ static void free_plan(mi_spmm_handle *h)
     if (h->d_chunks) (void)hipFree(h->d_chunks);
     if (h->d_long) (void)hipFree(h->d_long);
     if (h->d_partials) (void)hipFree(h->d_partials);
+    if (h->d_blk_flag) (void)hipFree(h->d_blk_flag);
+    if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
+    h->d_blk_flag = nullptr;
+    h->d_blk_groups = nullptr;
+    h->n_blk_groups = 0;
     h->d_chunks = nullptr;
     h->d_long = nullptr;
     h->d_partials = nullptr;
@@ -115,7 +125,8 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->xcd_remap = 1;
     h->nt_store = 1;
     h->nt_stream = 1;
-    h->block_path = 0;
+    h->block_path = 1;
+    h->block_min_len = 8;
     *out = h;
     return MI_SPMM_OK;
 }
@@ -151,7 +162,8 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "xcd_remap") h->xcd_remap = v ? 1 : 0;
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
-    else if (k == "block_path") { if (v) return MI_SPMM_EUNSUPPORTED; h->block_path = 0; }
+    else if (k == "block_path") { h->block_path = v ? 1 : 0; free_plan(h); }
+    else if (k == "block_min_len") { if (v < 1) return MI_SPMM_EINVAL; h->block_min_len = v; free_plan(h); }
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
 }
@@ -175,7 +187,8 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_launches") *value = h->last_launches;
     else if (k == "lanes_per_row") *value = h->last_lpr;
     else if (k == "vector_width") *value = h->last_v;
-    else if (k == "n_block_groups") *value = 0;
+    else if (k == "n_block_groups") *value = h->n_blk_groups;
+    else if (k == "block_min_len") *value = h->block_min_len;
     else if (k == "preprocess_us") *value = (int64_t)h->preprocess_us;
     else if (k == "prepared") *value = h->prepared ? 1 : 0;
     else return MI_SPMM_EUNSUPPORTED;
@@ -226,6 +239,34 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         (void)hipFree(d_bad);
         if (e != hipSuccess) return (int)e;
         if (bad) return MI_SPMM_ECSR;
+    }
+
+    // block path: 16-row groups with one shared column list (min_len <= L <= split threshold)
+    {
+        const int32_t N = h->feat;
+        const bool n_ok = (N == 32 || N == 64 || N == 128 || (N >= 256 && N % 256 == 0));
+        if (h->block_path && n_ok && M >= 16 && h->nnz > 0) {
+            const int32_t n_groups = (M + 15) / 16;
+            if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
+            const int grid = (n_groups + 3) / 4;  // one wave per group
+            hipLaunchKernelGGL(detect_row_blocks, dim3(grid), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M,
+                               (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
+            hipError_t e = hipGetLastError();
+            std::vector<uint8_t> flags((size_t)n_groups);
+            if (e == hipSuccess) e = hipMemcpy(flags.data(), h->d_blk_flag, (size_t)n_groups, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { free_plan(h); return (int)e; }
+            std::vector<int32_t> groups;
+            for (int32_t g = 0; g < n_groups; ++g) if (flags[(size_t)g]) groups.push_back(g);
+            if (groups.empty()) {
+                (void)hipFree(h->d_blk_flag);
+                h->d_blk_flag = nullptr;
+            } else {
+                if (hipMalloc((void **)&h->d_blk_groups, groups.size() * sizeof(int32_t)) != hipSuccess) { free_plan(h); return MI_SPMM_ENOMEM; }
+                e = hipMemcpy(h->d_blk_groups, groups.data(), groups.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+                if (e != hipSuccess) { free_plan(h); return (int)e; }
+                h->n_blk_groups = (int32_t)groups.size();
+            }
+        }
     }
 
     // long rows -> chunk table (the reference's Task list, spmm_opt.cu:43-54,
@@ -352,6 +393,20 @@ void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s)
     }
 }
 
+template <bool WIDE>
+void launch_blocks_w(int N, const BlockArgs &a, dim3 grid, hipStream_t s)
+{
+    if (N == 32) hipLaunchKernelGGL((spmm_blocks<2, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (N == 64) hipLaunchKernelGGL((spmm_blocks<4, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (N == 128) hipLaunchKernelGGL((spmm_blocks<8, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else hipLaunchKernelGGL((spmm_blocks<16, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+}
+void launch_blocks(int N, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
+{
+    if (wide) launch_blocks_w<true>(N, a, grid, s);
+    else launch_blocks_w<false>(N, a, grid, s);
+}
+
 int pow2_ceil(int x)
 {
     int p = 1;
@@ -421,7 +476,27 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ++launches;
     }
 
+    const bool blocks_on = h->n_blk_groups > 0 && vec4;
+    if (blocks_on && do_long) {
+        BlockArgs ba;
+        ba.groups = h->d_blk_groups;
+        ba.row_ptr = h->d_ptr;
+        ba.col_idx = h->d_idx;
+        ba.vals = h->d_val;
+        ba.B = d_vin;
+        ba.C = d_vout;
+        ba.ldb = ldb;
+        ba.ldc = ldc;
+        ba.n_groups = h->n_blk_groups;
+        ba.N = N;
+        const int slabs = N >= 256 ? N / 256 : 1;
+        dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
+        launch_blocks(N, wide, ba, bgrid, s);
+        ++launches;
+    }
+
     RowsArgs a;
+    a.blk_flag = blocks_on ? h->d_blk_flag : nullptr;
     a.row_ptr = h->d_ptr;
     a.col_idx = h->d_idx;
     a.vals = h->d_val;

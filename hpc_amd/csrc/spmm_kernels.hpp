@@ -38,6 +38,7 @@ struct RowsArgs {
     int32_t long_thr;       // rows with more nonzeros are left to the chunk path
     int32_t nblk;           // gridDim.x (for the XCD remap)
     int32_t flags;          // kFlagXcdRemap
+    const uint8_t *blk_flag; // per 16-row group: 1 = owned by the block (MFMA) path; may be null
 };
 
 struct Chunk {              // one <=long_chunk-nonzero piece of a long row
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_rows(RowsArgs a)
             end = __builtin_amdgcn_readfirstlane(end);
         }
         if (end - beg > a.long_thr) continue;  // chunk path owns this row
+        if (a.blk_flag && a.blk_flag[r >> 4]) continue;  // block path owns this 16-row group
         typename Vec<V>::T acc = segment_chain<V, LPR, UNROLL, WIDE, (POL & kPolNtStream) != 0>(
             a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
         if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)r * a.ldc + col, acc);
@@ -290,6 +292,168 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
     typename Vec<V>::T acc = Vec<V>::load(p);
     for (int i = 1; i < L.n_chunks; ++i) acc = Vec<V>::add(acc, Vec<V>::load(p + (int64_t)i * a.ldp));
     Vec<V>::template store<true>(a.C + (int64_t)L.row * a.ldc + col, acc);
+}
+
+// ---- block path: 16-row groups with one shared column list -----------------------
+// Detection: group g = rows [16g, 16g+16) qualifies when all 16 rows have the same
+// length L >= min_len and identical column sequences.  Then
+//     C[16 x N] = Avals[16 x L] * B[cols[0..L)][N]
+// is a small dense GEMM whose B operand is shared by the 16 rows: each B row is
+// fetched ONCE per group instead of 16 times.
+__global__ __launch_bounds__(kBlockThreads) void detect_row_blocks(const int32_t *__restrict__ row_ptr,
+                                                                  const int32_t *__restrict__ col_idx,
+                                                                  int32_t M, int32_t min_len, int32_t max_len,
+                                                                  uint8_t *__restrict__ flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = (int)((blockIdx.x * (unsigned)kBlockThreads + threadIdx.x) >> 6);  // one wave per group
+    const int n_groups = (M + 15) >> 4;
+    if (g >= n_groups) return;
+    const int r0 = g << 4;
+    bool qualifies = false;
+    if (r0 + 16 <= M) {
+        const int p = row_ptr[r0 + min(lane, 16)];            // lanes 0..16 hold ptr[r0 .. r0+16]
+        int ps[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) ps[i] = __builtin_amdgcn_readlane(p, i);  // wave-uniform row starts
+        const int L = ps[1] - ps[0];
+        bool ok = L >= min_len && L <= max_len;
+#pragma unroll
+        for (int i = 1; i < 16; ++i) ok = ok && (ps[i + 1] - ps[i] == L);
+        if (ok) {                                              // uniform branch
+            bool same = true;
+            for (int k = lane; k < L; k += 64) {
+                const int c0 = col_idx[ps[0] + k];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) same = same && (col_idx[ps[i] + k] == c0);
+            }
+            qualifies = __all(same);
+        }
+    }
+    if (lane == 0) flag[g] = qualifies ? 1 : 0;
+}
+
+struct BlockArgs {
+    const int32_t *groups;   // compacted list of qualifying group indices
+    const int32_t *row_ptr;
+    const int32_t *col_idx;
+    const float *vals;
+    const float *B;
+    float *C;
+    int64_t ldb;
+    int64_t ldc;
+    int32_t n_groups;
+    int32_t N;
+};
+
+typedef float float4a __attribute__((ext_vector_type(4)));
+
+// Lanes of a wave that exchange data through their private LDS slice: order the
+// compiler's view of the accesses (the hardware executes one wave's LDS
+// instructions in order, so no counter wait is needed for visibility).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One wave per 16-row group and 16*TILES-column slab (blockIdx.y = slab).
+//   v_mfma_f32_16x16x4_f32: A lane l = A[i = l&15][k = l>>4], B lane l = B[k = l>>4][j = l&15],
+//   D reg q of lane l = D[row 4*(l>>4)+q][col l&15]; the result is a k-ordered fp32 fma chain,
+//   so with k ascending per output element the block path is bit-identical to the rows path.
+// Per batch of KT k-rows: 8 x global_load_dwordx4 (8 KiB of B, full rows, coalesced) -> registers
+// -> ds_write_b128 into the wave's LDS slice (row pitch N_slab+16 floats: the 4 k-rows of an MFMA
+// operand land on disjoint banks) -> per 4-k step one A-fragment dword and TILES x (ds_read_b32 +
+// MFMA).  The next batch's global loads are issued before the current batch's MFMAs.
+template <int TILES, bool WIDE>
+__global__ __launch_bounds__(kBlockThreads, 4) void spmm_blocks(BlockArgs a)
+{
+    constexpr int NS = 16 * TILES;        // slab width in floats
+    constexpr int LPRB = NS / 4;          // lanes per B row (16 B each)
+    constexpr int RPI = 64 / LPRB;        // B rows per load instruction
+    constexpr int LOADS = 8;
+    constexpr int KT = LOADS * RPI;       // k-rows per batch
+    constexpr int KS = KT / 4;            // MFMA k-steps per batch
+    constexpr int SLD = NS + 16;          // LDS row pitch (floats), == 16 mod 32
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * KT * SLD];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gi = (int)blockIdx.x * 4 + wave;
+    if (gi >= a.n_groups) return;
+    float *lds = lds_all + wave * (KT * SLD);
+    const int g = a.groups[gi];
+    const int r0 = g << 4;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int slab0 = (int)blockIdx.y * NS;
+
+    const int p0 = __builtin_amdgcn_readfirstlane(a.row_ptr[r0]);
+    const int L = __builtin_amdgcn_readfirstlane(a.row_ptr[r0 + 1]) - p0;
+    const int my_row_start = a.row_ptr[r0 + i16];
+
+    const int q_in = lane / LPRB;                  // which of the RPI rows of a load this lane serves
+    const int colv = slab0 + 4 * (lane % LPRB);    // first of this lane's 4 columns
+    const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colv * 4u;
+
+    float4a acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = (float4a){0.f, 0.f, 0.f, 0.f};
+
+    float4v R[LOADS];
+    float af[KS];
+
+    auto prefetch = [&](int kb) {
+        // column indices of this batch: lane j holds cols[kb + j]
+        const int kk = kb + lane;
+        const int cj = (lane < KT && kk < L) ? a.col_idx[p0 + kk] : 0;
+#pragma unroll
+        for (int u = 0; u < LOADS; ++u) {
+            const int j = u * RPI + q_in;
+            const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
+            R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = kb + 4 * s + kq;
+            af[s] = (k < L) ? a.vals[my_row_start + k] : 0.f;
+        }
+    };
+
+    prefetch(0);
+    for (int kb = 0; kb < L; kb += KT) {
+        // registers -> LDS (rows past L were zero-filled: 0 * 0 terms are exact no-ops)
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < LOADS; ++u) {
+            const int j = u * RPI + q_in;
+            *reinterpret_cast<float4v *>(lds + j * SLD + 4 * (lane % LPRB)) = R[u];
+        }
+        float acur[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acur[s] = af[s];
+        wave_lds_sync();
+        if (kb + KT < L) prefetch(kb + KT);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s], b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // D reg q of lane l -> C[r0 + 4*kq + q][slab0 + 16t + i16]
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const int col = slab0 + 16 * t + i16;
+        if (col < a.N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_nontemporal_store(acc[t][q], a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + col);
+        }
+    }
 }
 
 // ---- CSR sanity: column range (an out-of-range column would fault the GPU) ----

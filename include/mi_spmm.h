@@ -111,7 +111,8 @@ const char *mi_spmm_strerror(int code);
  *   "xcd_remap"           0/1: contiguous row ranges per XCD
  *   "nt_store"            0/1: non-temporal stores of C
  *   "nt_stream"           0/1: non-temporal loads of col_idx/vals
- *   "block_path"          0/1: allow the block-dense MFMA path
+ *   "block_path"          0/1: 16-row groups sharing one column list go through the MFMA path
+ *   "block_min_len"       shortest shared column list the block path takes
  * set before preprocess; get any time.  Read-only keys after preprocess:
  *   "n_long_rows", "n_chunks", "workspace_bytes", "n_launches",
  *   "n_block_groups", "lanes_per_row", "preprocess_us" */

@@ -227,3 +227,97 @@ def test_reference_kernel_agrees_with_oracle_live(device, oracle):
     from hpc_amd import valid
     d_o = torch.from_numpy(ours).to(device)
     assert valid(d_o, d_C, M * N) == 0
+
+
+# ---- block (MFMA) path: 16-row groups sharing one column list --------------------------------
+def _shared_list_case(n_groups, K, N, seed, lens=None, tail_rows=5):
+    """Groups of 16 rows sharing a random (unsorted, possibly repeated) column list of random
+    length, interleaved with ordinary ragged rows; M is not a multiple of 16."""
+    g = np.random.Generator(np.random.Philox(key=[seed, 0]))
+    ptr = [0]
+    idx = []
+    kinds = []
+    for b in range(n_groups):
+        kind = int(g.integers(0, 3))            # 0: shared list, 1: ragged rows, 2: same length but one row differs
+        L = int(lens[b % len(lens)]) if lens is not None else int(g.integers(1, 200))
+        if kind == 0:
+            cols = g.integers(0, K, size=L)
+            for _ in range(16):
+                idx.append(cols)
+                ptr.append(ptr[-1] + L)
+        elif kind == 1:
+            for _ in range(16):
+                d = int(g.integers(0, 40))
+                idx.append(np.sort(g.choice(K, d, replace=False)))
+                ptr.append(ptr[-1] + d)
+        else:
+            cols = g.integers(0, K, size=L)
+            for r in range(16):
+                c = cols.copy()
+                if r == 11:
+                    c[L // 2] = (c[L // 2] + 1) % K
+                idx.append(c)
+                ptr.append(ptr[-1] + L)
+        kinds.append((kind, L))
+    for _ in range(tail_rows):
+        d = int(g.integers(1, 30))
+        idx.append(np.sort(g.choice(K, d, replace=False)))
+        ptr.append(ptr[-1] + d)
+    ptr = np.asarray(ptr, np.int32)
+    idx = np.concatenate(idx).astype(np.int32)
+    vals = synth.normal_f32(idx.size, seed + 1)
+    B = synth.normal_f32(K * N, seed + 2).reshape(K, N)
+    return ptr, idx, vals, B, kinds
+
+
+@pytest.mark.parametrize("N", [32, 64, 128, 256, 512])
+def test_block_path_bitwise(device, oracle, N):
+    ptr, idx, vals, B, kinds = _shared_list_case(60, 3000, N, seed=300 + N)
+    ref = oracle.spmm_omp(ptr, idx, vals, B)
+    C, op = run_spmm(device, ptr, idx, vals, B)
+    expect_groups = sum(1 for k, L in kinds if k == 0 and 8 <= L <= 512)
+    assert op.get_option("n_block_groups") == expect_groups and expect_groups > 5
+    assert not np.isnan(C).any()
+    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).sum()} of {C.size} differ"
+    C0, op0 = run_spmm(device, ptr, idx, vals, B, options={"block_path": 0})
+    assert op0.get_option("n_block_groups") == 0
+    assert np.array_equal(bits(C0), bits(ref))
+
+
+@pytest.mark.parametrize("L", [8, 9, 11, 12, 31, 32, 33, 64, 65, 127, 256, 257, 500])
+def test_block_path_list_lengths(device, oracle, L):
+    """Every tail shape of the k loop (batches of 8/16/32/64 k-rows, MFMA k-steps of 4)."""
+    for N in (32, 128, 256):
+        ptr, idx, vals, B, kinds = _shared_list_case(9, 700, N, seed=900 + L, lens=[L])
+        C, op = run_spmm(device, ptr, idx, vals, B)
+        assert op.get_option("n_block_groups") == sum(1 for k, _ in kinds if k == 0)
+        assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (L, N)
+
+
+def test_block_path_on_block_dense_config(device, oracle):
+    """BASELINE configs[4] family (down-sized): every row >= 64 contiguous nonzeros, N = 256."""
+    ptr, idx = synth.csr_block_dense_fast(8192)
+    vals = synth.normal_f32(idx.size, 6)
+    B = synth.normal_f32(8192 * 256, 7).reshape(8192, 256)
+    C, op = run_spmm(device, ptr, idx, vals, B)
+    assert op.get_option("n_block_groups") == 8192 // 16
+    assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+
+
+def test_block_path_with_row_panels_and_pitches(device, oracle):
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx, vals, B, kinds = _shared_list_case(40, 2000, 128, seed=77)
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    wide = torch.full((M, 256), float("nan"), dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), 128, num_cols=2000)
+    op.preprocess(d_B, wide)
+    assert op.get_option("n_block_groups") > 0
+    for r0, r1 in ((0, 200), (200, 456), (456, M)):
+        op.run_rows(d_B, 128, wide.view(-1)[128:], 256, r0, r1)     # right half of a wider C
+    torch.cuda.synchronize()
+    got = wide[:, 128:].cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+    assert torch.isnan(wide[:, :128]).all()
