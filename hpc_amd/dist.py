@@ -71,13 +71,14 @@ class ColumnShardedSpMM:
     caller owns), C_full[M][G*n_loc] = all blocks, row-major, identical on every rank."""
 
     def __init__(self, op, layout: ShardLayout, unpack: Callable, n_panels: int = 8,
-                 group=None, use_streams: Optional[bool] = None):
+                 group=None, use_streams: Optional[bool] = None, force_collective: bool = False):
         self.op = op
         self.layout = layout
         self.unpack = unpack
         self.group = group
         self.panels = row_panels(layout.M, n_panels)
         self.use_streams = use_streams
+        self.force_collective = force_collective  # run the gather pipeline even at world == 1 (rehearsal)
         self._staging = None
         self._streams = None
 
@@ -99,7 +100,7 @@ class ColumnShardedSpMM:
         import torch.distributed as dist
 
         L = self.layout
-        if L.world == 1:
+        if L.world == 1 and not self.force_collective:
             # nothing to exchange: the local block IS C
             self.op.run_rows(B_loc, L.n_loc, C_full, L.N_total, 0, L.M)
             return

@@ -321,3 +321,39 @@ def test_block_path_with_row_panels_and_pitches(device, oracle):
     got = wide[:, 128:].cpu().numpy()
     assert np.array_equal(bits(got), bits(oracle.spmm_omp(ptr, idx, vals, B)))
     assert torch.isnan(wide[:, :128]).all()
+
+
+def test_gather_pipeline_on_gpu_streams(device, oracle):
+    """The multi-GPU step's device side (compute stream / comm stream / staging / unpack kernel),
+    rehearsed on one GPU with a world_size-1 RCCL group forced through the collective path."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd.dist import ColumnShardedSpMM, ShardLayout
+    from hpc_amd.spmm import unpack_gathered
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        M, n_loc = 5000, 128
+        ptr, idx = synth.csr_powerlaw(M, 24.0, 2000, seed=8)       # includes split rows
+        vals = synth.normal_f32(idx.size, 9)
+        B = synth.normal_f32(M * n_loc, 10).reshape(M, n_loc)
+        d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
+        C_loc = torch.empty(M, n_loc, device=device)
+        C_full = torch.full((M, n_loc), float("nan"), device=device)
+        op.preprocess(d_B, C_loc)
+        sh = ColumnShardedSpMM(op, ShardLayout(M, n_loc, 1, 0), unpack_gathered, n_panels=5, force_collective=True)
+        for _ in range(3):
+            sh.run(d_B, C_loc, C_full)
+        torch.cuda.synchronize()
+        exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+        assert np.array_equal(bits(C_full.cpu().numpy()), bits(exp))
+    finally:
+        if created:
+            dist.destroy_process_group()
