@@ -598,6 +598,31 @@ int mi_spmm_count_bitdiff(const float *d_a, const float *d_b, int64_t n, int64_t
     return compare_common(d_a, d_b, n, 2, ndiff_out, maxabs_out, stream);
 }
 
+int mi_spmm_fill_normal(float *d_out, int64_t n, uint64_t seed, uint64_t subsequence, float mean, float stddev,
+                        void *stream)
+{
+    if (n < 0) return MI_SPMM_EINVAL;
+    if (n == 0) return MI_SPMM_OK;
+    if (!d_out) return MI_SPMM_EINVAL;
+    const int64_t want = ((n + 3) / 4 + kBlockThreads - 1) / kBlockThreads;
+    const int grid = (int)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
+    hipLaunchKernelGGL(fill_normal_kernel, dim3(grid), dim3(kBlockThreads), 0, (hipStream_t)stream, d_out, n, seed,
+                       subsequence, mean, stddev);
+    return (int)hipGetLastError();
+}
+
+int mi_spmm_fill_philox_u32(uint32_t *d_out, int64_t n, uint64_t seed, uint64_t subsequence, void *stream)
+{
+    if (n < 0) return MI_SPMM_EINVAL;
+    if (n == 0) return MI_SPMM_OK;
+    if (!d_out) return MI_SPMM_EINVAL;
+    const int64_t want = ((n + 3) / 4 + kBlockThreads - 1) / kBlockThreads;
+    const int grid = (int)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
+    hipLaunchKernelGGL(fill_philox_kernel, dim3(grid), dim3(kBlockThreads), 0, (hipStream_t)stream, d_out, n, seed,
+                       subsequence);
+    return (int)hipGetLastError();
+}
+
 int mi_spmm_unpack_gathered(const float *d_staging, float *d_C, int64_t rows, int32_t n_ranks,
                             int32_t n_loc, int64_t ldc, void *stream)
 {

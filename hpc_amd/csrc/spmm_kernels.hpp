@@ -367,7 +367,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // operand land on disjoint banks) -> per 4-k step one A-fragment dword and TILES x (ds_read_b32 +
 // MFMA).  The next batch's global loads are issued before the current batch's MFMAs.
 template <int TILES, bool WIDE>
-__global__ __launch_bounds__(kBlockThreads, 4) void spmm_blocks(BlockArgs a)
+__global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_blocks(BlockArgs a)
 {
     constexpr int NS = 16 * TILES;        // slab width in floats
     constexpr int LPRB = NS / 4;          // lanes per B row (16 B each)
@@ -509,6 +509,75 @@ __global__ __launch_bounds__(kBlockThreads) void compare_kernel(const void *ya, 
     if ((threadIdx.x & 63) == 0) {
         if (local) atomicAdd(count, local);
         if (maxabs_bits && lmax > 0.f) atomicMax(maxabs_bits, __float_as_uint(lmax));  // non-negative floats order as uints
+    }
+}
+
+// ---- device fill: fp32 N(mean, stddev) -- data.h:24-37 (curandGenerateNormal) --------
+// Counter-based Philox4x32-10 (Salmon et al., SC11; the Random123 constants) + Box-Muller.
+// Element i is a pure function of (seed, subsequence, i): block 4*(i/4) uses counter
+// {lo(i/4), hi(i/4), lo(subseq), hi(subseq)} and key {lo(seed), hi(seed)}; words (x0,x1)
+// give elements 4b, 4b+1 and (x2,x3) give 4b+2, 4b+3.  The distribution is the
+// reference's; cuRAND's XORWOW bit stream is not reproducible without cuRAND.
+struct Philox4 { uint32_t x[4]; };
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Philox4 o;
+    o.x[0] = c0; o.x[1] = c1; o.x[2] = c2; o.x[3] = c3;
+    return o;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float mean, float stddev, float &z0, float &z1)
+{
+    const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);         // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    z0 = r * cs * stddev + mean;
+    z1 = r * sn * stddev + mean;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void fill_normal_kernel(float *__restrict__ out, int64_t n,
+                                                                   uint64_t seed, uint64_t subseq,
+                                                                   float mean, float stddev)
+{
+    const int64_t nblk = (n + 3) >> 2;
+    for (int64_t b = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x; b < nblk;
+         b += (int64_t)gridDim.x * kBlockThreads) {
+        const Philox4 p = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)subseq,
+                                        (uint32_t)(subseq >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+        float z[4];
+        box_muller(p.x[0], p.x[1], mean, stddev, z[0], z[1]);
+        box_muller(p.x[2], p.x[3], mean, stddev, z[2], z[3]);
+        const int64_t i = b << 2;
+        if (i + 3 < n && ((uintptr_t)(out + i) & 15u) == 0) {
+            *reinterpret_cast<float4v *>(out + i) = (float4v){z[0], z[1], z[2], z[3]};
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) out[i + j] = z[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void fill_philox_kernel(uint32_t *__restrict__ out, int64_t n,
+                                                                   uint64_t seed, uint64_t subseq)
+{
+    const int64_t nblk = (n + 3) >> 2;
+    for (int64_t b = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x; b < nblk;
+         b += (int64_t)gridDim.x * kBlockThreads) {
+        const Philox4 p = philox4x32_10((uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)subseq,
+                                        (uint32_t)(subseq >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int j = 0; j < 4; ++j)
+            if ((b << 2) + j < n) out[(b << 2) + j] = p.x[j];
     }
 }
 

@@ -219,3 +219,34 @@ def unpack_gathered(staging, C_out, rows, n_ranks, n_loc, ldc):
         lib.mi_spmm_unpack_gathered(_ptr(staging), _ptr(C_out), int(rows), int(n_ranks), int(n_loc), int(ldc), _stream()),
         "mi_spmm_unpack_gathered",
     )
+
+
+def allocate(num, tensor_ptr=None, random=True, device="cuda", seed=123, subsequence=0):
+    """`allocate<float>(num, &tensor_ptr, random)` of include/data.h:24-37: a device buffer of
+    roundup512(num) floats, filled with N(0, 0.1) when `random` (seed 123 as test/main.cpp:20)."""
+    import torch
+
+    n = (int(num) + 511) // 512 * 512
+    t = torch.empty(n, dtype=torch.float32, device=device)
+    if random:
+        fill_normal(t, seed=seed, subsequence=subsequence, mean=0.0, stddev=0.1)
+    if tensor_ptr is not None:
+        tensor_ptr.append(t)
+    return t
+
+
+def fill_normal(t, seed=123, subsequence=0, mean=0.0, stddev=0.1):
+    import torch
+
+    _require_device("t", t, torch.float32)
+    _check(_lib.load().mi_spmm_fill_normal(_ptr(t), t.numel(), int(seed), int(subsequence), float(mean), float(stddev), _stream()),
+           "mi_spmm_fill_normal")
+    return t
+
+
+def fill_philox_u32(t, seed=123, subsequence=0):
+    import torch
+
+    _require_device("t", t, torch.int32)
+    _check(_lib.load().mi_spmm_fill_philox_u32(_ptr(t), t.numel(), int(seed), int(subsequence), _stream()), "mi_spmm_fill_philox_u32")
+    return t

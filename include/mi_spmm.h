@@ -134,6 +134,18 @@ int mi_spmm_valid_int(const int32_t *d_y, const int32_t *d_y2, int64_t n,
 int mi_spmm_count_bitdiff(const float *d_a, const float *d_b, int64_t n,
                           int64_t *ndiff_out, float *maxabs_out, void *stream);
 
+/* Replaces the fill half of allocate<T>() (include/data.h:24-37: cudaMalloc2 +
+ * curandGenerateNormal(kCuRand, p, n, 0.f, 0.1), generator seeded 123 in
+ * test/main.cpp:19-20): fp32 N(mean, stddev) written on the device.  Counter-based
+ * Philox4x32-10 + Box-Muller: element i depends only on (seed, subsequence, i), so any
+ * slice can be regenerated anywhere.  Same distribution as the reference; cuRAND's
+ * XORWOW bit stream itself is not reproducible without cuRAND. */
+int mi_spmm_fill_normal(float *d_out, int64_t n, uint64_t seed, uint64_t subsequence,
+                        float mean, float stddev, void *stream);
+/* The raw Philox4x32-10 words behind mi_spmm_fill_normal (known-answer testable). */
+int mi_spmm_fill_philox_u32(uint32_t *d_out, int64_t n, uint64_t seed, uint64_t subsequence,
+                            void *stream);
+
 /* Column-shard plumbing for the multi-GPU all-gather.
  * RCCL all-gather delivers rank-major blocks  staging[G][rows][n_loc];
  * this writes them into row-major C[rows][ldc] at column g*n_loc. */

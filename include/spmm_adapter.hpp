@@ -109,6 +109,30 @@ private:
     hipStream_t stream_ = nullptr;
 };
 
+#ifdef MI_SPMM_WITH_COMPARATOR
+#include "mi_spmm_comparator.h"
+// spmm_cusparse.h:6-24 -- the vendor comparator (rocSPARSE here); link libmi_spmm_rocsparse.so
+class SpMMRocSparse : public SpMM {
+public:
+    SpMMRocSparse(int *p, int *i, int nv, int ne, int f) : SpMM(p, i, nv, ne, f) {}
+    SpMMRocSparse(CSR *g, int out_feat_in) : SpMM(g, out_feat_in) {}
+    ~SpMMRocSparse() override
+    {
+        if (h_) (void)mi_rocsparse_spmm_destroy(h_);
+    }
+    void preprocess(float *vin, float *vout) override
+    {
+        if (!h_) MI_CHECK(mi_rocsparse_spmm_create(&h_, d_ptr, d_idx, d_val, num_v, num_v, num_e, feat_in, 0));
+        MI_CHECK(mi_rocsparse_spmm_preprocess(h_, vin, vout, nullptr));
+    }
+    void run(float *vin, float *vout) override { MI_CHECK(mi_rocsparse_spmm_run(h_, vin, vout, nullptr)); }
+
+private:
+    mi_rocsparse_spmm *h_ = nullptr;
+};
+using SpMMCuSparse = SpMMRocSparse;  // the reference harness's name for it (test_spmm.cu:48)
+#endif
+
 // valid.h / valid.cu:22-51
 inline int valid(float *y, float *y2, int num)
 {

@@ -185,6 +185,32 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def philox_block(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().oracle_philox_block(c, k, o)
+    return [int(x) for x in o]
+
+
+def fill_philox_u32(n, seed, subseq=0):
+    out = np.empty(int(n), dtype=np.uint32)
+    f = lib().oracle_fill_philox_u32
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64]
+    f.restype = None
+    f(_p(out), int(n), int(seed), int(subseq))
+    return out
+
+
+def fill_normal(n, seed, subseq=0, mean=0.0, stddev=0.1):
+    out = np.empty(int(n), dtype=np.float32)
+    f = lib().oracle_fill_normal
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, C.c_float]
+    f.restype = None
+    f(_p(out), int(n), int(seed), int(subseq), float(mean), float(stddev))
+    return out
+
+
 def fnv1a64(a):
     a = np.ascontiguousarray(a)
     return int(lib().oracle_fnv1a64(_p(a), a.nbytes))

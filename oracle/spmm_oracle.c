@@ -184,6 +184,57 @@ int oracle_num_threads(void)
 #endif
 }
 
+/* CPU restatement of the device fill (include/mi_spmm.h mi_spmm_fill_normal; the
+ * reference's counterpart is curandGenerateNormal in include/data.h:31): Philox4x32-10
+ * (Salmon, Moraes, Dror, Shaw, SC'11; Random123 constants and round function) keyed by
+ * (seed, subsequence, i/4) + Box-Muller.  The integer stream is bit-exact; the normals
+ * agree with the device up to libm-vs-ocml rounding of logf/sincosf (tests: 1e-6 abs). */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+void oracle_philox_block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox4x32_10(c, key[0], key[1]);
+    for (int j = 0; j < 4; ++j) out[j] = c[j];
+}
+
+void oracle_fill_philox_u32(uint32_t *out, int64_t n, uint64_t seed, uint64_t subseq)
+{
+    for (int64_t b = 0; b < (n + 3) / 4; ++b) {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)subseq, (uint32_t)(subseq >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int j = 0; j < 4; ++j)
+            if (4 * b + j < n) out[4 * b + j] = c[j];
+    }
+}
+
+void oracle_fill_normal(float *out, int64_t n, uint64_t seed, uint64_t subseq, float mean, float stddev)
+{
+    for (int64_t b = 0; b < (n + 3) / 4; ++b) {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)subseq, (uint32_t)(subseq >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = (float)((c[2 * h] >> 8) + 1u) * (1.0f / 16777216.0f);
+            const float u2 = (float)(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-2.0f * logf(u1));
+            const float ang = 6.28318530717958647692f * u2;
+            const float z0 = r * cosf(ang) * stddev + mean, z1 = r * sinf(ang) * stddev + mean;
+            if (4 * b + 2 * h < n) out[4 * b + 2 * h] = z0;
+            if (4 * b + 2 * h + 1 < n) out[4 * b + 2 * h + 1] = z1;
+        }
+    }
+}
+
 /* FNV-1a 64 over raw bytes: checksum-of-outputs for large cases. */
 uint64_t oracle_fnv1a64(const void *data, int64_t nbytes)
 {

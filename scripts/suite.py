@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ref", action="store_true")
+    ap.add_argument("--vendor", action="store_true", help="also time rocSPARSE (the reference's headline comparator)")
     ap.add_argument("--M", type=int, default=1 << 20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--opt", action="append", default=[])
@@ -84,6 +85,21 @@ def main():
                    "GBs_min_model": round(model["bytes_min"] / ms / 1e6, 1),
                    "n_long_rows": op.get_option("n_long_rows"), "n_chunks": op.get_option("n_chunks"),
                    "lanes_per_row": op.get_option("lanes_per_row"), "preprocess_us": op.get_option("preprocess_us"), "gen_s": round(gen_s, 1)}
+            if args.vendor:
+                from hpc_amd.comparator import SpMMRocSparse
+                from hpc_amd import valid as _valid
+                d_V = torch.full((M, N), float("nan"), device=dev)
+                try:
+                    vs = SpMMRocSparse(CSR(M, nnz, d_ptr, d_idx, d_val), N)
+                    vs.preprocess(d_B, d_V)
+                    row["rocsparse_ms"] = round(timed(lambda: vs.run(d_B, d_V), 2, 5), 4)
+                    row["speedup_vs_rocsparse"] = round(row["rocsparse_ms"] / ms, 2)
+                    row["rocsparse_valid_bad"] = _valid(d_C, d_V, M * N)
+                    row["rocsparse_buffer_bytes"] = vs.buffer_bytes()
+                    del vs
+                except Exception as e:  # comparator trouble must not hide our own numbers
+                    row["rocsparse_error"] = str(e)[:100]
+                del d_V
             if args.ref and oracle.ref_available():
                 d_R = torch.zeros((M, N), device=dev)
                 if N <= 1024:

@@ -105,3 +105,22 @@ def test_oracle_reproduces_reference_kernel_goldens(oracle, path):
     )
     out2 = oracle.spmm_omp(z["row_ptr"], z["col_idx"], z["vals"], z["B"])
     assert np.array_equal(out2.view(np.uint32), exp.view(np.uint32))
+
+
+def test_philox4x32_10_known_answers(oracle):
+    """Random123 kat_vectors for philox4x32-10: pins the generator behind mi_spmm_fill_normal."""
+    assert oracle.philox_block([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert oracle.philox_block([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert oracle.philox_block([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_fill_normal_restatement_statistics(oracle):
+    z = oracle.fill_normal(1 << 20, 123, 0, 0.0, 0.1).astype(np.float64)
+    assert abs(z.mean()) < 5e-4 and abs(z.std() - 0.1) < 5e-4        # N(0, 0.1): data.h:31
+    assert abs((z ** 3).mean()) < 2e-5 and abs((z ** 4).mean() / 0.1 ** 4 - 3.0) < 0.05
+    assert np.isfinite(z).all() and np.abs(z).max() < 0.62            # |z| <= 0.1*sqrt(2*24*ln2)
+    a = oracle.fill_normal(1001, 5, 7)
+    b = oracle.fill_normal(4000, 5, 7)
+    assert np.array_equal(a, b[:1001])                                # element i depends on (seed, subseq, i) only
+    assert not np.array_equal(oracle.fill_normal(64, 5, 8), b[:64])

@@ -357,3 +357,85 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_device_fill_matches_restatement(device, oracle):
+    """allocate<T>()'s fill (data.h:24-37): device Philox stream bit-exact, normals within libm/ocml rounding."""
+    import torch
+    from hpc_amd.spmm import allocate, fill_normal, fill_philox_u32
+
+    for n in (1, 3, 4, 5, 1023, 1 << 16):
+        u = torch.empty(n, dtype=torch.int32, device=device)
+        fill_philox_u32(u, seed=123, subsequence=9)
+        assert np.array_equal(u.cpu().numpy().view(np.uint32), oracle.fill_philox_u32(n, 123, 9))
+        z = torch.full((n,), float("nan"), device=device)
+        fill_normal(z, seed=77, subsequence=2, mean=0.5, stddev=2.0)
+        assert np.abs(z.cpu().numpy() - oracle.fill_normal(n, 77, 2, 0.5, 2.0)).max() <= 2e-5   # stddev 2.0: 1e-6 * scale
+    t = allocate(1000)                       # rounds up to 1024 floats, N(0, 0.1), seed 123
+    assert t.numel() == 1024
+    ref = oracle.fill_normal(1024, 123, 0, 0.0, 0.1)
+    assert np.abs(t.cpu().numpy() - ref).max() <= 1e-6
+    z = allocate(1 << 22).double()
+    assert abs(z.mean().item()) < 3e-4 and abs(z.std().item() - 0.1) < 3e-4
+    # unaligned start (a view one float in): scalar tail path
+    buf = torch.zeros(4099, device=device)
+    fill_normal(buf[1:4098], seed=1)
+    torch.cuda.synchronize()
+    assert buf[0].item() == 0.0 and buf[4098].item() == 0.0
+    assert np.abs(buf[1:4098].cpu().numpy() - oracle.fill_normal(4097, 1)).max() <= 1e-6
+
+
+def test_rocsparse_comparator_agrees(device, oracle):
+    """SpMMCuSparse's counterpart (spmm_cusparse.cu:3-34): an independent GPU-side value check, held to the
+    reference's own acceptance rule (valid.cu:6, test_spmm.cu:43)."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt, valid
+    from hpc_amd.comparator import SpMMRocSparse
+
+    M, N = 30000, 64
+    ptr, idx, vals, B = _rand_case(M, M, N, 0, 64, seed=55)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    g = CSR(M, idx.size, d_ptr, d_idx, d_val)
+    d_C = torch.full((M, N), float("nan"), device=device)
+    d_R = torch.full((M, N), float("nan"), device=device)
+    ours = SpMMOpt(g, N)
+    ours.preprocess(d_B, d_C)
+    ours.run(d_B, d_C)
+    vend = SpMMRocSparse(g, N)
+    vend.preprocess(d_B, d_R)
+    vend.run(d_B, d_R)
+    vend.run(d_B, d_R)          # beta = 0: idempotent
+    torch.cuda.synchronize()
+    bad = valid(d_C, d_R, M * N)
+    assert oracle.validation_passes(bad, M, N), bad
+    _, sabs = oracle.spmm_f64(ptr, idx, vals, B)
+    assert (np.abs(d_R.cpu().numpy().astype(np.float64) - oracle.spmm_omp(ptr, idx, vals, B)) <= 1e-5 * sabs + 1e-30).all()
+
+
+def test_native_harness_end_to_end(device, tmp_path):
+    """The reference's `unit_tests` flow (test/main.cpp + test/test_spmm.cu) re-stated natively over the C++
+    adapter: course-format graph files in, gtest-shaped output and plot.py-parsable log lines out."""
+    import re
+    import subprocess
+    from hpc_amd import graph_io
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "unit_tests")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "native")])
+    ptr, idx = synth.csr_powerlaw(30000, 20.0, 1500, seed=12)
+    graph_io.write_graph(str(tmp_path), "syn", ptr, idx, text=True, dumps=False)
+    for n_len, has_cache in ((32, False), (256, True)):
+        r = subprocess.run([exe, "--dataset", "syn", "--datadir", str(tmp_path), "--len", str(n_len)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "[  PASSED  ] 3 tests." in r.stdout
+        for t in ("validation", "cusparse_performance", "opt_performance"):
+            assert f"[       OK ] SpMMTest.{t}" in r.stdout
+        # the reference's own log scrapers (plot.py:13-14)
+        assert re.search(r"dset = \"([\w\.]*)\"", r.stderr).group(1) == "syn"
+        times = [float(m) for m in re.findall(r"time = ([\d\.]*) \(double\)", r.stderr)]
+        assert len(times) == 2 and all(0 < t < 1 for t in times)
+        m = re.search(r"bad = (\d+) \(int\)\s+bitdiff = (\d+)", r.stderr)
+        assert int(m.group(1)) < 30000 * n_len // 10000 + 1
+        assert os.path.exists(tmp_path / "syn.graph.ptrdump") and os.path.exists(tmp_path / "syn.graph.edgedump")
