@@ -215,14 +215,14 @@ def main():
                             f"N={n_total} fp32 ({n_loc} columns per GPU), int32 indices",
                 "M": M, "K": M, "nnz": nnz, "N": n_total, "cols_per_gpu": n_loc,
                 "parallelism": "single GPU" if world == 1 else f"column-sharded x{world}, RCCL all-gather of C blocks, {args.panels} row panels",
-                "options": {k: op.get_option(k) for k in ("unroll", "rows_per_block", "xcd_remap", "nt_store", "nt_stream",
+                "options": {k: op.get_option(k) for k in ("kernel", "unroll", "rows_per_block", "block_threads", "xcd_remap", "nt_store", "nt_stream",
                                                           "long_row_threshold", "long_row_chunk", "n_long_rows", "n_chunks",
                                                           "lanes_per_row", "vector_width", "n_launches")},
                 "preprocess_ms": round(t_pre * 1e3, 2), "input_gen_s": round(t_gen, 1),
             },
             "device_ms_per_step": round(dev_ms_mean, 4),
             "roofline": ({
-                "bound": "hbm", "kernel": "mi::spmm_rows", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "mi::spmm_rows_v2" if op.get_option("kernel") == 2 else "mi::spmm_rows", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_alg_per_launch": model["bytes_alg"], "bytes_min_per_launch": model["bytes_min"],
                 "kernel_ms": round(dev_ms_mean, 4),
@@ -275,6 +275,9 @@ def sweep(args, op, step, M, N, nnz):
     grids = {
         "knobs": dict(unroll=[4, 8, 16], nt_store=[0, 1], nt_stream=[0, 1], xcd_remap=[0, 1], rows_per_block=[0]),
         "rpb": dict(unroll=[8], nt_store=[1], nt_stream=[1], xcd_remap=[1], rows_per_block=[8, 16, 32, 64, 128, 256, 1024]),
+        "bt": dict(kernel=[2], nt_store=[1], nt_stream=[0], xcd_remap=[0, 1], block_threads=[64, 128, 256], rpg=[1, 2]),
+        "rpg": dict(kernel=[2], nt_store=[1], nt_stream=[0, 1], xcd_remap=[1], rpg=[1, 2, 3, 4, 8, 16]),
+        "v2": dict(kernel=[1, 2], nt_store=[0, 1], nt_stream=[0, 1], xcd_remap=[0, 1], rpg=[2, 4, 7]),
     }[args.sweep]
     keys = list(grids)
     combos = list(itertools.product(*[grids[k] for k in keys]))
@@ -283,7 +286,11 @@ def sweep(args, op, step, M, N, nnz):
     for r in range(rounds):
         for c in combos:
             for k, v in zip(keys, c):
-                op.set_option(k, v)
+                if k == "rpg":   # rows per lane group -> rows per block
+                    bt = dict(zip(keys, c)).get("block_threads", 256)
+                    op.set_option("rows_per_block", v * max(1, bt // max(8, min(64, N // 4))))
+                else:
+                    op.set_option(k, v)
             for _ in range(2):
                 step()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -30,6 +30,8 @@ struct mi_spmm_handle {
     int64_t nnz;
     // options
     int64_t long_thr, long_chunk, unroll, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
+    int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
+    int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -121,12 +123,14 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->long_thr = 512;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->unroll = 8;
-    h->rows_per_block = 0; // auto
-    h->xcd_remap = 1;
-    h->nt_store = 1;
-    h->nt_stream = 1;
+    h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
+    h->xcd_remap = -1;     // auto: on while a row is narrower than a wave (N <= 128), off otherwise
+    h->nt_store = 1;       // C is write-once
+    h->nt_stream = 0;      // (col,val) fetches straddle lines: nt would drop the line before its other half is used
     h->block_path = 1;
     h->block_min_len = 8;
+    h->kernel = 2;
+    h->block_threads = 256;
     *out = h;
     return MI_SPMM_OK;
 }
@@ -159,7 +163,9 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "long_row_chunk") { if (v < 1) return MI_SPMM_EINVAL; h->long_chunk = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "unroll") { if (v != 4 && v != 8 && v != 16) return MI_SPMM_EINVAL; h->unroll = v; }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
-    else if (k == "xcd_remap") h->xcd_remap = v ? 1 : 0;
+    else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
+    else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
+    else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
     else if (k == "block_path") { h->block_path = v ? 1 : 0; free_plan(h); }
@@ -177,6 +183,8 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "unroll") *value = h->unroll;
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
+    else if (k == "kernel") *value = h->kernel;
+    else if (k == "block_threads") *value = h->block_threads;
     else if (k == "nt_store") *value = h->nt_store;
     else if (k == "nt_stream") *value = h->nt_stream;
     else if (k == "block_path") *value = h->block_path;
@@ -363,6 +371,47 @@ void launch_rows_fixed(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
     default: launch_rows_k<V, 64, 8, WIDE, 3>(a, grid, s); break;
     }
 }
+template <int LPR, int BT>
+void launch_rows_v2_pol(int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
+{
+    switch (pol & 3) {
+    case 0: hipLaunchKernelGGL((spmm_rows_v2<4, LPR, 8, false, 0, BT>), grid, dim3(BT), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((spmm_rows_v2<4, LPR, 8, false, 1, BT>), grid, dim3(BT), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((spmm_rows_v2<4, LPR, 8, false, 2, BT>), grid, dim3(BT), 0, s, a); break;
+    default: hipLaunchKernelGGL((spmm_rows_v2<4, LPR, 8, false, 3, BT>), grid, dim3(BT), 0, s, a); break;
+    }
+}
+template <int LPR>
+void launch_rows_v2_bt(int bt, int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
+{
+    if (bt == 64) launch_rows_v2_pol<LPR, 64>(pol, a, grid, s);
+    else if (bt == 128) launch_rows_v2_pol<LPR, 128>(pol, a, grid, s);
+    else launch_rows_v2_pol<LPR, 256>(pol, a, grid, s);
+}
+template <int V, bool WIDE>
+void launch_rows_v2_fixed(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
+{
+    switch (lpr) {
+    case 8: hipLaunchKernelGGL((spmm_rows_v2<V, 8, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((spmm_rows_v2<V, 16, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((spmm_rows_v2<V, 32, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((spmm_rows_v2<V, 64, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
+    }
+}
+void launch_rows_v2_any(bool vec4, bool wide, int lpr, int bt, int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
+{
+    if (vec4 && !wide) {
+        switch (lpr) {
+        case 8: launch_rows_v2_bt<8>(bt, pol, a, grid, s); break;
+        case 16: launch_rows_v2_bt<16>(bt, pol, a, grid, s); break;
+        case 32: launch_rows_v2_bt<32>(bt, pol, a, grid, s); break;
+        default: launch_rows_v2_bt<64>(bt, pol, a, grid, s); break;
+        }
+    } else if (vec4) launch_rows_v2_fixed<4, true>(lpr, a, grid, s);
+    else if (wide) launch_rows_v2_fixed<1, true>(lpr, a, grid, s);
+    else launch_rows_v2_fixed<1, false>(lpr, a, grid, s);
+}
+
 void launch_rows_any(bool vec4, bool wide, int lpr, int unroll, int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
 {
     if (vec4 && !wide) {
@@ -443,13 +492,20 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     if (lpr > 64) lpr = 64;
     const int tile_w = lpr * V;
     const int col_tiles = (N + tile_w - 1) / tile_w;
-    const int gpb = kBlockThreads / lpr;
+    const bool v2 = h->kernel == 2;
+    const int bt = (v2 && vec4 && !wide) ? (int)h->block_threads : kBlockThreads;
+    const int gpb = bt / lpr;
     int rpb = (int)h->rows_per_block;
-    if (rpb <= 0) rpb = gpb * 8;  // 8 rows per lane group per block
+    if (rpb <= 0) rpb = v2 ? gpb : gpb * 8;  // v2: one row per lane group; v1: 8
     if (rpb < gpb) rpb = gpb;
+    int rpg = rpb / gpb;          // v2: contiguous rows per lane group, at most LPR - 1
+    if (rpg > lpr - 1) rpg = lpr - 1;
+    if (rpg < 1) rpg = 1;
+    if (v2) rpb = rpg * gpb;
     const int64_t nblk64 = ((int64_t)(row_end - row_begin) + rpb - 1) / rpb;
     if (nblk64 > INT32_MAX || col_tiles > 65535) return MI_SPMM_EUNSUPPORTED;
-    const int flags = h->xcd_remap ? kFlagXcdRemap : 0;
+    const bool remap = h->xcd_remap < 0 ? (lpr < 64) : (h->xcd_remap != 0);
+    const int flags = remap ? kFlagXcdRemap : 0;
     const int pol = (h->nt_store ? kPolNtStore : 0) | (h->nt_stream ? kPolNtStream : 0);
     int launches = 0;
 
@@ -468,7 +524,8 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ca.n_chunks = h->n_chunks;
         ca.N = N;
         ca.flags = flags;
-        dim3 cgrid((h->n_chunks + gpb - 1) / gpb, col_tiles);
+        const int cgpb = kBlockThreads / lpr;  // the chunk kernel always runs 256-thread workgroups
+        dim3 cgrid((h->n_chunks + cgpb - 1) / cgpb, col_tiles);
         // partial rows are ldp (multiple of 4) floats and hipMalloc-aligned, so only
         // the B side decides the vector width here
         if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, s); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, s); }
@@ -507,12 +564,13 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     a.row0 = row_begin;
     a.M = row_end;
     a.N = N;
-    a.rows_per_block = rpb;
+    a.rows_per_block = v2 ? rpg : rpb;
     a.long_thr = (int32_t)h->long_thr;
     a.nblk = (int)nblk64;
     a.flags = flags;
     dim3 grid((unsigned)nblk64, col_tiles);
-    launch_rows_any(vec4, wide, lpr, (int)h->unroll, pol, a, grid, s);
+    if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
+    else launch_rows_any(vec4, wide, lpr, (int)h->unroll, pol, a, grid, s);
     ++launches;
 
     if (h->n_long > 0 && do_long) {

@@ -230,6 +230,164 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_rows(RowsArgs a)
     }
 }
 
+// ---- rows kernel v2: same arithmetic, software-pipelined over (row, chunk) items ----
+// v1 above serialises three memory round trips per row (row_ptr -> (col,val) -> B rows) and
+// fetches only LPR pairs at a time, which starves narrow groups (N = 32: 8 pairs per fetch).
+// v2 gives every lane group a CONTIGUOUS run of rows, so
+//   * the group's row pointers arrive in one coalesced load at kernel start;
+//   * its nonzeros form one contiguous stream, fetched CH = 32 (64) pairs at a time -- lanes of
+//     narrow groups load PV = 32/LPR consecutive pairs each (dwordx2/x4, 4-byte aligned);
+//   * the fetch of the NEXT item (next chunk of this row, or first chunk of the next row) is
+//     issued before the current item's B-row loads, so B gathers run back to back.
+// The per-element operand order is untouched: still one fma chain per row in stored order.
+template <int PV> struct Pairs {
+    int ci[PV];
+    int av[PV];  // float bits
+};
+
+template <int PV, bool NT>
+__device__ __forceinline__ Pairs<PV> fetch_pairs(const int32_t *__restrict__ col_idx,
+                                                 const float *__restrict__ vals, int kk, int kend)
+{
+    typedef int ivec __attribute__((ext_vector_type(PV), aligned(4)));
+    Pairs<PV> p;
+#pragma unroll
+    for (int i = 0; i < PV; ++i) { p.ci[i] = 0; p.av[i] = 0; }
+    if (PV > 1 && kk + PV <= kend) {
+        ivec c, v;
+        if (NT) {
+            c = __builtin_nontemporal_load(reinterpret_cast<const ivec *>(col_idx + kk));
+            v = __builtin_nontemporal_load(reinterpret_cast<const ivec *>(vals + kk));
+        } else {
+            c = *reinterpret_cast<const ivec *>(col_idx + kk);
+            v = *reinterpret_cast<const ivec *>(vals + kk);
+        }
+#pragma unroll
+        for (int i = 0; i < PV; ++i) { p.ci[i] = c[i]; p.av[i] = v[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            if (kk + i < kend) {
+                if (NT) {
+                    p.ci[i] = __builtin_nontemporal_load(col_idx + kk + i);
+                    p.av[i] = __float_as_int(__builtin_nontemporal_load(vals + kk + i));
+                } else {
+                    p.ci[i] = col_idx[kk + i];
+                    p.av[i] = __float_as_int(vals[kk + i]);
+                }
+            }
+        }
+    }
+    return p;
+}
+
+template <int V, int LPR, int UNROLL, bool WIDE, int POL, int BT>
+__global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
+{
+    constexpr int GPB = BT / LPR;
+    constexpr int PV = (LPR >= 32) ? 1 : (32 / LPR);
+    constexpr int CH = LPR * PV;  // pairs per fetch: 32 (64 when the group is the whole wave)
+    constexpr bool NTS = (POL & kPolNtStream) != 0;
+    static_assert(UNROLL % PV == 0, "a batch must cover whole fetch lanes");
+    typedef typename Vec<V>::T T;
+    const int tid = threadIdx.x;
+    const int g = tid / LPR;
+    const int lig = tid % LPR;
+    const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(blockIdx.x, a.nblk) : (int)blockIdx.x;
+    const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
+    const bool col_ok = col_raw < a.N;
+    const int col = col_ok ? col_raw : a.N - V;
+    const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)col * 4u;
+
+    const int rpg = a.rows_per_block;  // here: rows per lane GROUP (<= LPR - 1)
+    const int gbase = a.row0 + (vb * GPB + g) * rpg;
+    int nrows = a.M - gbase;
+    nrows = nrows > rpg ? rpg : nrows;
+    if (nrows <= 0) return;
+    // lane i of the group holds row_ptr[gbase + i], i = 0..nrows
+    const int myptr = a.row_ptr[gbase + min(lig, nrows)];
+    unsigned f0 = 0, f1 = 0;
+    if (a.blk_flag) {
+        f0 = a.blk_flag[gbase >> 4];
+        f1 = a.blk_flag[(gbase + nrows - 1) >> 4];
+    }
+    auto mine = [&](int ri, int rbeg, int rend) -> bool {
+        const unsigned f = (((gbase + ri) >> 4) == (gbase >> 4)) ? f0 : f1;
+        return (rend - rbeg <= a.long_thr) && f == 0;
+    };
+
+    int ri = 0;
+    int k0 = group_bcast<LPR>(myptr, 0);
+    int end = group_bcast<LPR>(myptr, 1);
+    bool live = mine(0, k0, end);
+    Pairs<PV> cur = fetch_pairs<PV, NTS>(a.col_idx, a.vals, k0 + lig * PV, live ? end : k0);
+    T acc = Vec<V>::zero();
+    for (;;) {
+        // ---- what comes after this item, and its fetch (in flight while we gather B rows)
+        const bool last = !live || (k0 + CH >= end);
+        int nri = ri, nk0 = k0 + CH, nend = end;
+        bool nlive = live;
+        bool has_next = true;
+        if (last) {
+            nri = ri + 1;
+            has_next = nri < nrows;
+            if (has_next) {
+                nk0 = group_bcast<LPR>(myptr, nri);
+                nend = group_bcast<LPR>(myptr, nri + 1);
+                nlive = mine(nri, nk0, nend);
+            }
+        }
+        Pairs<PV> nxt;
+#pragma unroll
+        for (int i = 0; i < PV; ++i) { nxt.ci[i] = 0; nxt.av[i] = 0; }
+        if (has_next) nxt = fetch_pairs<PV, NTS>(a.col_idx, a.vals, nk0 + lig * PV, nlive ? nend : nk0);
+
+        // ---- this item: up to CH nonzeros of row gbase + ri, in stored order
+        if (live) {
+            const int cnt = min(CH, end - k0);
+            int jb = 0;
+            for (; jb + UNROLL <= cnt; jb += UNROLL) {
+                T b[UNROLL];
+                float av[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int src = jb / PV + u / PV;
+                    const int c = group_bcast<LPR>(cur.ci[u % PV], src);
+                    av[u] = __int_as_float(group_bcast<LPR>(cur.av[u % PV], src));
+                    b[u] = Vec<V>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, col, c));
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
+            }
+            if (UNROLL > 1 && jb < cnt) {
+                T b[UNROLL];
+                float av[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL - 1; ++u) {
+                    const int src = jb / PV + u / PV;
+                    const int c = group_bcast<LPR>(cur.ci[u % PV], src);
+                    av[u] = __int_as_float(group_bcast<LPR>(cur.av[u % PV], src));
+                    b[u] = Vec<V>::zero();
+                    if (jb + u < cnt) b[u] = Vec<V>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, col, c));
+                }
+                // slots past cnt carry a = +0, b = +0 (unfetched pairs are zero): exact no-ops
+#pragma unroll
+                for (int u = 0; u < UNROLL - 1; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
+            }
+            if (last) {
+                if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)(gbase + ri) * a.ldc + col, acc);
+                acc = Vec<V>::zero();
+            }
+        }
+        if (!has_next) break;
+        ri = nri;
+        k0 = nk0;
+        end = nend;
+        live = nlive;
+        cur = nxt;
+    }
+}
+
 // ---- chunks kernel: long rows, one lane group per chunk ----------------------
 struct ChunkArgs {
     const Chunk *chunks;

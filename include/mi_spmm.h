@@ -107,8 +107,10 @@ const char *mi_spmm_strerror(int code);
  *   "long_row_threshold"  rows with more nonzeros are split into chunks
  *   "long_row_chunk"      chunk length in nonzeros
  *   "unroll"              B-row loads in flight per lane group (4,8,16)
- *   "rows_per_block"      rows handled by one 256-thread workgroup
- *   "xcd_remap"           0/1: contiguous row ranges per XCD
+ *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
+ *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
+ *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto (on for N <= 128)
+ *   "kernel"              1: per-row fetch (spmm_rows), 2: pipelined items (spmm_rows_v2, default)
  *   "nt_store"            0/1: non-temporal stores of C
  *   "nt_stream"           0/1: non-temporal loads of col_idx/vals
  *   "block_path"          0/1: 16-row groups sharing one column list go through the MFMA path

@@ -33,11 +33,12 @@ def test_goldens_bitwise(device, path):
 def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
     M, K = 777, 513
     ptr, idx, vals, B = _rand_case(M, K, N, 0, 70, seed=100 + N)
-    C, op = run_spmm(device, ptr, idx, vals, B)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
-    assert not np.isnan(C).any(), "output not fully overwritten"
-    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).sum()} elements differ"
-    assert op.get_option("vector_width") == (4 if N % 4 == 0 else 1)
+    for kernel in (1, 2):
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"kernel": kernel})
+        assert not np.isnan(C).any(), "output not fully overwritten"
+        assert np.array_equal(bits(C), bits(ref)), f"kernel {kernel}: {(bits(C) != bits(ref)).sum()} elements differ"
+        assert op.get_option("vector_width") == (4 if N % 4 == 0 else 1)
 
 
 @pytest.mark.parametrize("unroll", [4, 8, 16])
@@ -46,18 +47,20 @@ def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
 def test_bitwise_over_tuning_knobs(device, oracle, unroll, pol, N):
     ptr, idx, vals, B = _rand_case(2000, 2000, N, 0, 90, seed=7)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
-    for rpb, xcd in ((0, 1), (16, 0), (1000, 1)):
+    for rpb, xcd, kernel in ((0, 1, 1), (16, 0, 1), (1000, 1, 1), (0, 1, 2), (8, 0, 2), (1000, 0, 2)):
         C, _ = run_spmm(device, ptr, idx, vals, B, options={
-            "unroll": unroll, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd})
-        assert np.array_equal(bits(C), bits(ref))
+            "unroll": unroll, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd,
+            "kernel": kernel})
+        assert np.array_equal(bits(C), bits(ref)), (rpb, xcd, kernel)
 
 
 def test_edge_shapes(device, oracle):
     # M = 1; all rows empty; a single nonzero; K != M; nnz = 0
     for (M, K, N, lo, hi, seed) in [(1, 1, 4, 1, 1, 1), (5, 9, 8, 0, 0, 2), (1, 300, 128, 200, 200, 3), (300, 7, 16, 0, 7, 4), (64, 64, 128, 64, 64, 5)]:
         ptr, idx, vals, B = _rand_case(M, K, N, lo, hi, seed)
-        C, _ = run_spmm(device, ptr, idx, vals, B)
-        assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (M, K, N)
+        for kernel in (1, 2):
+            C, _ = run_spmm(device, ptr, idx, vals, B, options={"kernel": kernel})
+            assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (M, K, N, kernel)
 
 
 def test_empty_matrix_and_zero_width(device):
