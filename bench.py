@@ -275,6 +275,7 @@ def sweep(args, op, step, M, N, nnz):
     grids = {
         "knobs": dict(unroll=[4, 8, 16], nt_store=[0, 1], nt_stream=[0, 1], xcd_remap=[0, 1], rows_per_block=[0]),
         "rpb": dict(unroll=[8], nt_store=[1], nt_stream=[1], xcd_remap=[1], rows_per_block=[8, 16, 32, 64, 128, 256, 1024]),
+        "wide": dict(kernel=[1, 2], nt_store=[1], nt_stream=[0], xcd_remap=[0, 1], rpg=[1, 2, 8]),
         "bt": dict(kernel=[2], nt_store=[1], nt_stream=[0], xcd_remap=[0, 1], block_threads=[64, 128, 256], rpg=[1, 2]),
         "rpg": dict(kernel=[2], nt_store=[1], nt_stream=[0, 1], xcd_remap=[1], rpg=[1, 2, 3, 4, 8, 16]),
         "v2": dict(kernel=[1, 2], nt_store=[0, 1], nt_stream=[0, 1], xcd_remap=[0, 1], rpg=[2, 4, 7]),

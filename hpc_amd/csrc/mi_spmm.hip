@@ -48,6 +48,7 @@ struct mi_spmm_handle {
     uint8_t *d_blk_flag;
     int32_t *d_blk_groups;
     int32_t n_blk_groups;
+    int64_t n_rows_for_rows_kernel;  // rows neither split nor owned by the block path
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
@@ -124,7 +125,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->unroll = 8;
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
-    h->xcd_remap = -1;     // auto: on while a row is narrower than a wave (N <= 128), off otherwise
+    h->xcd_remap = -1;     // auto (see run)
     h->nt_store = 1;       // C is write-once
     h->nt_stream = 0;      // (col,val) fetches straddle lines: nt would drop the line before its other half is used
     h->block_path = 1;
@@ -305,6 +306,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     }
     h->n_chunks = (int32_t)chunks.size();
     h->n_long = (int32_t)longs.size();
+    h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
     if (h->n_chunks > 0) {
         const size_t cb = chunks.size() * sizeof(Chunk), lb = longs.size() * sizeof(LongRow);
@@ -504,7 +506,9 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     if (v2) rpb = rpg * gpb;
     const int64_t nblk64 = ((int64_t)(row_end - row_begin) + rpb - 1) / rpb;
     if (nblk64 > INT32_MAX || col_tiles > 65535) return MI_SPMM_EUNSUPPORTED;
-    const bool remap = h->xcd_remap < 0 ? (lpr < 64) : (h->xcd_remap != 0);
+    // auto: measured neutral-to-positive everywhere except one whole-wave row and a single column
+    // tile (N = 256), where interleaving rows over the XCDs is ~3 % faster (profiles/r01_sweep_*)
+    const bool remap = h->xcd_remap < 0 ? !(lpr == 64 && col_tiles == 1) : (h->xcd_remap != 0);
     const int flags = remap ? kFlagXcdRemap : 0;
     const int pol = (h->nt_store ? kPolNtStore : 0) | (h->nt_stream ? kPolNtStream : 0);
     int launches = 0;
@@ -569,9 +573,12 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     a.nblk = (int)nblk64;
     a.flags = flags;
     dim3 grid((unsigned)nblk64, col_tiles);
-    if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
+    // every row may already be owned by the block path (and the split path): nothing left to launch
+    const bool rows_needed = !(blocks_on && h->n_rows_for_rows_kernel == 0);
+    if (!rows_needed) { /* skip */ }
+    else if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
     else launch_rows_any(vec4, wide, lpr, (int)h->unroll, pol, a, grid, s);
-    ++launches;
+    if (rows_needed) ++launches;
 
     if (h->n_long > 0 && do_long) {
         ReduceArgs ra;
