@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
         end = __builtin_amdgcn_readfirstlane(end);
     }
     typename Vec<V>::T acc =
-        segment_chain<V, LPR, UNROLL, WIDE, true>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
+        segment_chain<V, LPR, UNROLL, WIDE, false>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
     if (col_ok) Vec<V>::template store<false>(a.partials + (int64_t)c.slot * a.ldp + col, acc);
 }
 

@@ -159,6 +159,45 @@ def csr_block_dense_fast(M, rows_per_block=16, K=None, seed=SEED_STRUCT):
     return ptr.astype(np.int32), col.astype(np.int32)
 
 
+def csr_rmat(scale, edge_factor=32, a=0.57, b=0.19, c=0.19, seed=SEED_STRUCT):
+    """R-MAT / Kronecker graph (Chakrabarti, Zhan, Faloutsos 2004; Graph500 parameters): M = 2^scale rows,
+    about edge_factor * M edges before duplicate removal.  Hubs with 10^4..10^5 nonzeros next to empty rows --
+    the shape of the course's real graphs (max degree up to 154 828, W/phase_2.log), harsher than C2."""
+    M = 1 << scale
+    E = M * edge_factor
+    g = _rng(seed, 4)
+    rows = np.zeros(E, dtype=np.int64)
+    cols = np.zeros(E, dtype=np.int64)
+    for _ in range(scale):
+        r = g.random(E, dtype=np.float32)
+        rows = (rows << 1) | (r >= a + b)
+        cols = (cols << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c))
+    key = rows * np.int64(M) + cols
+    key = np.unique(key)
+    rows = key // np.int64(M)
+    cols = (key - rows * np.int64(M)).astype(np.int32)
+    ptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=M), out=ptr[1:])
+    assert ptr[-1] <= np.iinfo(np.int32).max
+    return ptr.astype(np.int32), cols
+
+
+def csr_banded(M, deg_lo=16, deg_hi=48, width=2048, seed=SEED_STRUCT):
+    """Locality-rich structure: row r's columns are drawn within +-width of r (community / mesh-like
+    adjacency): neighbouring rows share B rows, so L2 / Infinity Cache reuse exists to be had."""
+    g = _rng(seed, 5)
+    deg = g.integers(deg_lo, deg_hi + 1, size=M, dtype=np.int64)
+    rows = np.repeat(np.arange(M, dtype=np.int64), deg)
+    off = g.integers(-width, width + 1, size=rows.size, dtype=np.int64)
+    cols = np.clip(rows + off, 0, M - 1)
+    key = np.unique(rows * np.int64(M) + cols)
+    rows = key // np.int64(M)
+    cols = (key - rows * np.int64(M)).astype(np.int32)
+    ptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=M), out=ptr[1:])
+    return ptr.astype(np.int32), cols
+
+
 def make_values(nnz, seed=SEED_VALS):
     return normal_f32(nnz, seed, 0)
 

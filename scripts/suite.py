@@ -56,8 +56,11 @@ def main():
         "uniform32": lambda: synth.csr_uniform(M, 16, 48),
         "powerlaw32": lambda: synth.csr_powerlaw(M, 32.0, 4096),
         "blockdense": lambda: synth.csr_block_dense_fast(M),
+        "rmat": lambda: synth.csr_rmat(int(np.log2(M)), 32),
+        "banded": lambda: synth.csr_banded(M),
     }
-    plan = [("uniform32", [32, 64, 128, 256, 512, 1024]), ("powerlaw32", [32, 128, 256]), ("blockdense", [128, 256])]
+    plan = [("uniform32", [32, 64, 128, 256, 512, 1024]), ("powerlaw32", [32, 128, 256]), ("blockdense", [128, 256]),
+            ("rmat", [32, 128, 256]), ("banded", [32, 128, 256])]
     if args.quick:
         plan = [("uniform32", [32, 128, 256]), ("powerlaw32", [128]), ("blockdense", [256])]
     for sname, Ns in plan:

@@ -442,3 +442,55 @@ def test_native_harness_end_to_end(device, tmp_path):
         m = re.search(r"bad = (\d+) \(int\)\s+bitdiff = (\d+)", r.stderr)
         assert int(m.group(1)) < 30000 * n_len // 10000 + 1
         assert os.path.exists(tmp_path / "syn.graph.ptrdump") and os.path.exists(tmp_path / "syn.graph.edgedump")
+
+
+def test_run_is_graph_capturable_and_stream_ordered(device, oracle):
+    """run() allocates nothing and never synchronises: it can be captured into a HIP
+    graph and replayed, and it runs on the caller's stream (the reference: null stream, util.h:133-136)."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx = synth.csr_powerlaw(6000, 24.0, 2000, seed=3)      # rows + chunks + reduce: three launches
+    vals = synth.normal_f32(idx.size, 4)
+    B = synth.normal_f32(6000 * 64, 5).reshape(6000, 64)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((6000, 64), float("nan"), device=device)
+    op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
+    op.preprocess(d_B, d_C)
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        op.run(d_B, d_C)
+    side.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    assert op.get_option("n_launches") == 3
+    d_C.fill_(float("nan"))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        op.run(d_B, d_C)
+    d_C.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    # new B contents, same graph
+    d_B.mul_(2.0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
+
+
+def test_rmat_and_banded_structures(device, oracle):
+    """Hub-dominated (R-MAT) and locality-rich (banded) graphs: hubs go through the split path, everything
+    else stays bit-exact."""
+    for name, (ptr, idx) in {"rmat": synth.csr_rmat(14, 16, seed=2), "banded": synth.csr_banded(20000, 4, 40, width=300, seed=2)}.items():
+        M = ptr.size - 1
+        vals = synth.normal_f32(idx.size, 3)
+        B = synth.normal_f32(M * 64, 4).reshape(M, 64)
+        C, op = run_spmm(device, ptr, idx, vals, B)
+        exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+        assert np.array_equal(bits(C), bits(exp)), name
+        if name == "rmat":
+            assert op.get_option("n_long_rows") > 0 and (np.diff(ptr) == 0).any()
+            plain = oracle.spmm_omp(ptr, idx, vals, B)
+            _, sabs = oracle.spmm_f64(ptr, idx, vals, B)
+            assert (np.abs(C.astype(np.float64) - plain) <= TOL_SPLIT * sabs + 1e-30).all()
