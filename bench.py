@@ -93,6 +93,12 @@ def build_inputs(args, world, rank):
         ptr, idx = synth.csr_block_dense_fast(M)
         if not args.N and args.mode == "weak":
             n_loc, n_total = 256, 256 * world
+    elif name == "RMAT":
+        M = M or (1 << 20)
+        ptr, idx = synth.csr_rmat(int(np.log2(M)), 32)
+    elif name == "BANDED":
+        M = M or (1 << 20)
+        ptr, idx = synth.csr_banded(M)
     else:
         raise SystemExit(f"unknown config {name}")
     vals = synth.make_values(idx.size)

@@ -9,6 +9,7 @@
 #include "../../include/mi_spmm.h"
 #include "spmm_kernels.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -29,6 +30,7 @@ struct mi_spmm_handle {
     int32_t num_v, num_cols, feat;
     int64_t nnz;
     // options
+    int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel
     int64_t long_thr, long_chunk, unroll, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
@@ -37,7 +39,7 @@ struct mi_spmm_handle {
     Chunk *d_chunks;
     LongRow *d_long;
     float *d_partials;
-    int32_t n_chunks, n_long;
+    int32_t n_chunks, n_long, n_medium, n_slots;
     int64_t ldp;
     size_t ws_bytes;
     int32_t max_row_nnz;
@@ -68,7 +70,7 @@ static void free_plan(mi_spmm_handle *h)
     h->d_chunks = nullptr;
     h->d_long = nullptr;
     h->d_partials = nullptr;
-    h->n_chunks = h->n_long = 0;
+    h->n_chunks = h->n_long = h->n_medium = h->n_slots = 0;
     h->ws_bytes = 0;
     h->prepared = false;
 }
@@ -121,6 +123,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->num_cols = num_cols;
     h->nnz = nnz;
     h->feat = feat_in;
+    h->medium_thr = 64;
     h->long_thr = 512;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->unroll = 8;
@@ -160,7 +163,8 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
 {
     if (!good(h) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
-    if (k == "long_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->long_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+    if (k == "medium_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+    else if (k == "long_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->long_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_chunk") { if (v < 1) return MI_SPMM_EINVAL; h->long_chunk = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "unroll") { if (v != 4 && v != 8 && v != 16) return MI_SPMM_EINVAL; h->unroll = v; }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
@@ -180,6 +184,9 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     if (!good(h) || !key || !value) return MI_SPMM_EINVAL;
     const std::string k(key);
     if (k == "long_row_threshold") *value = h->long_thr;
+    else if (k == "medium_row_threshold") *value = h->medium_thr;
+    else if (k == "n_medium_rows") *value = h->n_medium;
+    else if (k == "n_partial_slots") *value = h->n_slots;
     else if (k == "long_row_chunk") *value = h->long_chunk;
     else if (k == "unroll") *value = h->unroll;
     else if (k == "rows_per_block") *value = h->rows_per_block;
@@ -278,47 +285,72 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         }
     }
 
-    // long rows -> chunk table (the reference's Task list, spmm_opt.cu:43-54,
-    // kept only for rows that need it and without the shuffle)
+    // Segment table (the reference's Task list, spmm_opt.cu:43-54, kept only for rows that need it):
+    //   len > long_thr                 -> pieces of long_chunk nonzeros, partial sums + ordered reduce
+    //   medium_thr < len <= long_thr   -> ONE segment = the whole row, stored straight to C (exact order)
+    // Rows of block-path groups are excluded (their L <= long_thr by construction).  Segments are
+    // sorted longest first: neighbours in a wave have similar lengths and the tail is short.
+    std::vector<uint8_t> flags_host;
+    if (h->n_blk_groups > 0) {
+        flags_host.resize((size_t)(M + 15) / 16);
+        HIP_TRY(hipMemcpy(flags_host.data(), h->d_blk_flag, flags_host.size(), hipMemcpyDeviceToHost));
+    }
     std::vector<Chunk> chunks;
     std::vector<LongRow> longs;
     const int32_t thr = (int32_t)h->long_thr, clen = (int32_t)h->long_chunk;
-    if (max_len > thr) {
+    const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);
+    int32_t n_slots = 0, n_medium = 0;
+    if (max_len > mthr) {
         for (int32_t r = 0; r < M; ++r) {
-            const int32_t beg = ptr[r], end = ptr[r + 1];
-            if (end - beg <= thr) continue;
+            const int32_t beg = ptr[r], end = ptr[r + 1], len = end - beg;
+            if (len <= mthr) continue;
+            if (len <= thr) {
+                if (!flags_host.empty() && flags_host[(size_t)(r >> 4)]) continue;  // block path owns it
+                Chunk c;
+                c.beg = beg;
+                c.end = end;
+                c.slot = -1;
+                c.row = r;
+                chunks.push_back(c);
+                ++n_medium;
+                continue;
+            }
             LongRow L;
             L.row = r;
-            L.first_slot = (int32_t)chunks.size();
+            L.first_slot = n_slots;
             L.n_chunks = 0;
             L.pad = 0;
             for (int32_t b = beg; b < end; b += clen) {
                 Chunk c;
                 c.beg = b;
                 c.end = (end - b > clen) ? b + clen : end;
-                c.slot = (int32_t)chunks.size();
+                c.slot = n_slots++;
                 c.row = r;
                 chunks.push_back(c);
                 ++L.n_chunks;
             }
             longs.push_back(L);
         }
+        std::stable_sort(chunks.begin(), chunks.end(),
+                         [](const Chunk &x, const Chunk &y) { return (x.end - x.beg) > (y.end - y.beg); });
     }
     h->n_chunks = (int32_t)chunks.size();
     h->n_long = (int32_t)longs.size();
-    h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long;
+    h->n_medium = n_medium;
+    h->n_slots = n_slots;
+    h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)n_medium;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
     if (h->n_chunks > 0) {
         const size_t cb = chunks.size() * sizeof(Chunk), lb = longs.size() * sizeof(LongRow);
-        const size_t pb = (size_t)h->n_chunks * (size_t)h->ldp * sizeof(float);
+        const size_t pb = (size_t)n_slots * (size_t)h->ldp * sizeof(float);
         if (hipMalloc((void **)&h->d_chunks, cb) != hipSuccess ||
-            hipMalloc((void **)&h->d_long, lb) != hipSuccess ||
+            hipMalloc((void **)&h->d_long, lb ? lb : 16) != hipSuccess ||
             hipMalloc((void **)&h->d_partials, pb ? pb : 16) != hipSuccess) {
             free_plan(h);
             return MI_SPMM_ENOMEM;
         }
         hipError_t e = hipMemcpy(h->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(h->d_long, longs.data(), lb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && lb) e = hipMemcpy(h->d_long, longs.data(), lb, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             free_plan(h);
             return (int)e;
@@ -523,8 +555,10 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ca.vals = h->d_val;
         ca.B = d_vin;
         ca.partials = h->d_partials;
+        ca.C = d_vout;
         ca.ldb = ldb;
         ca.ldp = h->ldp;
+        ca.ldc = ldc;
         ca.n_chunks = h->n_chunks;
         ca.N = N;
         ca.flags = flags;
@@ -569,7 +603,11 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     a.M = row_end;
     a.N = N;
     a.rows_per_block = v2 ? rpg : rpb;
-    a.long_thr = (int32_t)h->long_thr;
+    // rows above the medium threshold were given to the segment kernel -- except rows of block groups
+    // when the block path cannot run here (unaligned pointers): then the rows kernel takes every
+    // unsplit row again (medium rows are computed twice with identical bits; stream order keeps it benign)
+    const bool blocks_fallback = h->n_blk_groups > 0 && !blocks_on;
+    a.long_thr = (int32_t)(blocks_fallback ? h->long_thr : (h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr));
     a.nblk = (int)nblk64;
     a.flags = flags;
     dim3 grid((unsigned)nblk64, col_tiles);

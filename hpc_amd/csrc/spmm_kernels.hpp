@@ -41,11 +41,12 @@ struct RowsArgs {
     const uint8_t *blk_flag; // per 16-row group: 1 = owned by the block (MFMA) path; may be null
 };
 
-struct Chunk {              // one <=long_chunk-nonzero piece of a long row
+struct Chunk {              // one segment of one row, handled by one lane group
     int32_t beg;            // first nonzero (index into col_idx/vals)
     int32_t end;            // one past the last
-    int32_t slot;           // row of the partial-sum workspace it writes
-    int32_t row;            // CSR row it belongs to (debug / reduce cross-check)
+    int32_t slot;           // >= 0: row of the partial-sum workspace it writes (piece of a split row)
+                            //  < 0: the segment is the WHOLE row -> result goes straight to C[row]
+    int32_t row;            // CSR row it belongs to
 };
 
 struct LongRow {
@@ -281,6 +282,70 @@ __device__ __forceinline__ Pairs<PV> fetch_pairs(const int32_t *__restrict__ col
     return p;
 }
 
+// The fma chain over the first `cnt` pairs held by a group (pair j lives in lane j / PV,
+// component j % PV), continued from `acc`: batches of UNROLL B-row gathers, then the
+// dependent fmas in stored order.
+template <int V, int LPR, int PV, int UNROLL, bool WIDE>
+__device__ __forceinline__ typename Vec<V>::T
+item_chain(const Pairs<PV> &cur, int cnt, typename Vec<V>::T acc, const float *__restrict__ B, int64_t ldb,
+           uint32_t ldb_bytes, uint32_t col_bytes, int col)
+{
+    typedef typename Vec<V>::T T;
+    int jb = 0;
+    for (; jb + UNROLL <= cnt; jb += UNROLL) {
+        T b[UNROLL];
+        float av[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int src = jb / PV + u / PV;
+            const int c = group_bcast<LPR>(cur.ci[u % PV], src);
+            av[u] = __int_as_float(group_bcast<LPR>(cur.av[u % PV], src));
+            b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
+    }
+    if (UNROLL > 1 && jb < cnt) {
+        T b[UNROLL];
+        float av[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL - 1; ++u) {
+            const int src = jb / PV + u / PV;
+            const int c = group_bcast<LPR>(cur.ci[u % PV], src);
+            av[u] = __int_as_float(group_bcast<LPR>(cur.av[u % PV], src));
+            b[u] = Vec<V>::zero();
+            if (jb + u < cnt) b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
+        }
+        // slots past cnt carry a = +0, b = +0 (unfetched pairs are zero): exact no-ops
+#pragma unroll
+        for (int u = 0; u < UNROLL - 1; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
+    }
+    return acc;
+}
+
+// One segment [beg, end) of one row, pipelined: 32 (64) pairs per fetch, the next fetch in
+// flight while the current pairs' B rows are gathered.
+template <int V, int LPR, int UNROLL, bool WIDE, bool NT>
+__device__ __forceinline__ typename Vec<V>::T
+segment_chain_v2(const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
+                 const float *__restrict__ B, int64_t ldb, int col, int beg, int end, int lig)
+{
+    constexpr int PV = (LPR >= 32) ? 1 : (32 / LPR);
+    constexpr int CH = LPR * PV;
+    typename Vec<V>::T acc = Vec<V>::zero();
+    const uint32_t ldb_bytes = (uint32_t)ldb * 4u, col_bytes = (uint32_t)col * 4u;
+    Pairs<PV> cur = fetch_pairs<PV, NT>(col_idx, vals, beg + lig * PV, end);
+    for (int k0 = beg; k0 < end; k0 += CH) {
+        Pairs<PV> nxt;
+#pragma unroll
+        for (int i = 0; i < PV; ++i) { nxt.ci[i] = 0; nxt.av[i] = 0; }
+        if (k0 + CH < end) nxt = fetch_pairs<PV, NT>(col_idx, vals, k0 + CH + lig * PV, end);
+        acc = item_chain<V, LPR, PV, UNROLL, WIDE>(cur, min(CH, end - k0), acc, B, ldb, ldb_bytes, col_bytes, col);
+        cur = nxt;
+    }
+    return acc;
+}
+
 template <int V, int LPR, int UNROLL, bool WIDE, int POL, int BT>
 __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
 {
@@ -344,36 +409,7 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
 
         // ---- this item: up to CH nonzeros of row gbase + ri, in stored order
         if (live) {
-            const int cnt = min(CH, end - k0);
-            int jb = 0;
-            for (; jb + UNROLL <= cnt; jb += UNROLL) {
-                T b[UNROLL];
-                float av[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int src = jb / PV + u / PV;
-                    const int c = group_bcast<LPR>(cur.ci[u % PV], src);
-                    av[u] = __int_as_float(group_bcast<LPR>(cur.av[u % PV], src));
-                    b[u] = Vec<V>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, col, c));
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
-            }
-            if (UNROLL > 1 && jb < cnt) {
-                T b[UNROLL];
-                float av[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL - 1; ++u) {
-                    const int src = jb / PV + u / PV;
-                    const int c = group_bcast<LPR>(cur.ci[u % PV], src);
-                    av[u] = __int_as_float(group_bcast<LPR>(cur.av[u % PV], src));
-                    b[u] = Vec<V>::zero();
-                    if (jb + u < cnt) b[u] = Vec<V>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, col, c));
-                }
-                // slots past cnt carry a = +0, b = +0 (unfetched pairs are zero): exact no-ops
-#pragma unroll
-                for (int u = 0; u < UNROLL - 1; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
-            }
+            acc = item_chain<V, LPR, PV, UNROLL, WIDE>(cur, min(CH, end - k0), acc, a.B, a.ldb, ldb_bytes, col_bytes, col);
             if (last) {
                 if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)(gbase + ri) * a.ldc + col, acc);
                 acc = Vec<V>::zero();
@@ -394,9 +430,11 @@ struct ChunkArgs {
     const int32_t *col_idx;
     const float *vals;
     const float *B;
-    float *partials;       // [n_chunks][ldp]
+    float *partials;       // [n_partial_slots][ldp]
+    float *C;
     int64_t ldb;
     int64_t ldp;
+    int64_t ldc;
     int32_t n_chunks;
     int32_t N;
     int32_t flags;
@@ -421,8 +459,11 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
         end = __builtin_amdgcn_readfirstlane(end);
     }
     typename Vec<V>::T acc =
-        segment_chain<V, LPR, UNROLL, WIDE, false>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
-    if (col_ok) Vec<V>::template store<false>(a.partials + (int64_t)c.slot * a.ldp + col, acc);
+        segment_chain_v2<V, LPR, UNROLL, WIDE, false>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
+    if (col_ok) {
+        if (c.slot >= 0) Vec<V>::template store<false>(a.partials + (int64_t)c.slot * a.ldp + col, acc);
+        else Vec<V>::template store<true>(a.C + (int64_t)c.row * a.ldc + col, acc);
+    }
 }
 
 // ---- reduce kernel: C[row] = ((p0 + p1) + p2) + ...  in chunk order ----------

@@ -104,6 +104,7 @@ int mi_spmm_destroy(mi_spmm_handle *h);
 const char *mi_spmm_strerror(int code);
 
 /* Tuning / introspection.  Keys (all int64):
+ *   "medium_row_threshold" rows longer than this run as ONE exact segment in the segment kernel
  *   "long_row_threshold"  rows with more nonzeros are split into chunks
  *   "long_row_chunk"      chunk length in nonzeros
  *   "unroll"              B-row loads in flight per lane group (4,8,16)
