@@ -124,7 +124,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->nnz = nnz;
     h->feat = feat_in;
     h->medium_thr = 64;
-    h->long_thr = 512;
+    h->long_thr = 2048;    // rows up to here stay ONE exact segment; only hubs are split (profiles/r01_thresholds.txt)
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->unroll = 8;
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)

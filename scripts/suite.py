@@ -58,9 +58,10 @@ def main():
         "blockdense": lambda: synth.csr_block_dense_fast(M),
         "rmat": lambda: synth.csr_rmat(int(np.log2(M)), 32),
         "banded": lambda: synth.csr_banded(M),
+        "denseish": lambda: synth.csr_uniform(M // 4, 300, 700),
     }
     plan = [("uniform32", [32, 64, 128, 256, 512, 1024]), ("powerlaw32", [32, 128, 256]), ("blockdense", [128, 256]),
-            ("rmat", [32, 128, 256]), ("banded", [32, 128, 256])]
+            ("rmat", [32, 128, 256]), ("banded", [32, 128, 256]), ("denseish", [32, 128, 256])]
     if args.quick:
         plan = [("uniform32", [32, 128, 256]), ("powerlaw32", [128]), ("blockdense", [256])]
     for sname, Ns in plan:
@@ -71,6 +72,7 @@ def main():
         vals = synth.make_values(idx.size)
         deg = np.diff(ptr)
         nnz = int(idx.size)
+        M = ptr.size - 1
         d_ptr, d_idx, d_val = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals))
         gen_s = time.time() - t
         for N in Ns:

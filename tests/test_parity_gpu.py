@@ -88,8 +88,9 @@ def test_overwrite_and_idempotent(device, oracle):
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((3000, 64), 1e30, dtype=torch.float32, device=device)
     op = SpMMOpt(CSR(3000, idx.size, d_ptr, d_idx, d_val), 64)
+    op.set_option("long_row_threshold", 512)
     op.preprocess(d_B, d_C)
-    assert op.get_option("n_long_rows") > 0
+    assert op.get_option("n_long_rows") > 0 and op.get_option("n_medium_rows") > 0
     op.run(d_B, d_C)
     first = d_C.clone()
     for _ in range(3):
@@ -120,8 +121,12 @@ def test_power_law_rows(device, oracle):
     vals = synth.normal_f32(idx.size, 6)
     B = synth.normal_f32(20000 * 128, 7).reshape(20000, 128)
     C, op = run_spmm(device, ptr, idx, vals, B)
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+    assert op.get_option("long_row_threshold") == 2048 and op.get_option("n_long_rows") > 0
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, 2048, 256)
     assert np.array_equal(bits(C), bits(exp))
+    C5, op5 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512, "long_row_chunk": 100})
+    assert op5.get_option("n_long_rows") > op.get_option("n_long_rows")
+    assert np.array_equal(bits(C5), bits(oracle.spmm_chunked(ptr, idx, vals, B, 512, 100)))
     C2, _ = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 1 << 30})
     assert np.array_equal(bits(C2), bits(oracle.spmm_omp(ptr, idx, vals, B)))
 
@@ -278,7 +283,7 @@ def test_block_path_bitwise(device, oracle, N):
     ptr, idx, vals, B, kinds = _shared_list_case(60, 3000, N, seed=300 + N)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
     C, op = run_spmm(device, ptr, idx, vals, B)
-    expect_groups = sum(1 for k, L in kinds if k == 0 and 8 <= L <= 512)
+    expect_groups = sum(1 for k, L in kinds if k == 0 and 8 <= L <= 2048)
     assert op.get_option("n_block_groups") == expect_groups and expect_groups > 5
     assert not np.isnan(C).any()
     assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).sum()} of {C.size} differ"
@@ -348,6 +353,7 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
         B = synth.normal_f32(M * n_loc, 10).reshape(M, n_loc)
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
+        op.set_option("long_row_threshold", 300)
         C_loc = torch.empty(M, n_loc, device=device)
         C_full = torch.full((M, n_loc), float("nan"), device=device)
         op.preprocess(d_B, C_loc)
@@ -355,7 +361,7 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
         for _ in range(3):
             sh.run(d_B, C_loc, C_full)
         torch.cuda.synchronize()
-        exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+        exp = oracle.spmm_chunked(ptr, idx, vals, B, op.get_option("long_row_threshold"), op.get_option("long_row_chunk"))
         assert np.array_equal(bits(C_full.cpu().numpy()), bits(exp))
     finally:
         if created:
@@ -456,6 +462,7 @@ def test_run_is_graph_capturable_and_stream_ordered(device, oracle):
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((6000, 64), float("nan"), device=device)
     op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
+    op.set_option("long_row_threshold", 512)
     op.preprocess(d_B, d_C)
     exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
     side = torch.cuda.Stream(device=device)
@@ -486,7 +493,7 @@ def test_rmat_and_banded_structures(device, oracle):
         M = ptr.size - 1
         vals = synth.normal_f32(idx.size, 3)
         B = synth.normal_f32(M * 64, 4).reshape(M, 64)
-        C, op = run_spmm(device, ptr, idx, vals, B)
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512})
         exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
         assert np.array_equal(bits(C), bits(exp)), name
         if name == "rmat":
@@ -494,3 +501,39 @@ def test_rmat_and_banded_structures(device, oracle):
             plain = oracle.spmm_omp(ptr, idx, vals, B)
             _, sabs = oracle.spmm_f64(ptr, idx, vals, B)
             assert (np.abs(C.astype(np.float64) - plain) <= TOL_SPLIT * sabs + 1e-30).all()
+
+
+def test_fuzz_shapes_pitches_thresholds(device, oracle):
+    """80 seeded random cases: ragged shapes, K != M, odd widths, row pitches wider than N, both rows
+    kernels, random medium/split thresholds -- always bit-equal to the oracle in the documented order."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    g = np.random.Generator(np.random.Philox(key=[2024, 1]))
+    for case in range(80):
+        M = int(g.integers(1, 400))
+        K = int(g.integers(1, 500))
+        N = int(g.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 33, 64, 96, 128, 130, 256, 300]))
+        hi = int(g.choice([0, 3, 20, 90, min(K, 400)]))
+        ptr, idx = synth.csr_uniform(M, 0, min(hi, K), K=K, seed=1000 + case)
+        if idx.size and g.random() < 0.5:       # unsorted / duplicated columns inside rows
+            idx = g.integers(0, K, size=idx.size).astype(np.int32)
+        vals = synth.normal_f32(idx.size, 5000 + case)
+        ldb = N + int(g.choice([0, 0, 4, 5, 64]))
+        ldc = N + int(g.choice([0, 0, 4, 3, 128]))
+        Bp = synth.normal_f32(K * ldb, 9000 + case).reshape(K, ldb)
+        opts = {"kernel": int(g.choice([1, 2])), "medium_row_threshold": int(g.choice([1, 5, 64, 1000])),
+                "long_row_threshold": int(g.choice([6, 40, 2048])), "long_row_chunk": int(g.choice([3, 16, 256])),
+                "block_path": int(g.choice([0, 1]))}
+        d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
+        d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+        for k, v in opts.items():
+            op.set_option(k, v)
+        op.preprocess(d_B, d_C)
+        op.run_ld(d_B, ldb, d_C, ldc)
+        torch.cuda.synchronize()
+        got = d_C.cpu().numpy()
+        exp = oracle.spmm_chunked(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["long_row_threshold"], opts["long_row_chunk"])
+        assert np.array_equal(bits(got[:, :N]), bits(exp)), (case, M, K, N, ldb, ldc, opts)
+        assert np.isnan(got[:, N:]).all(), "wrote outside its N columns"
