@@ -44,6 +44,7 @@ struct mi_spmm_handle {
     size_t ws_bytes;
     int32_t max_row_nnz;
     double preprocess_us;
+    double phase_us[5];  // d2h row_ptr + validate, column check, block detection, host segment table, upload
     int32_t last_lpr, last_v, last_launches;
     // block (MFMA) path
     int64_t block_min_len;
@@ -206,6 +207,11 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_block_groups") *value = h->n_blk_groups;
     else if (k == "block_min_len") *value = h->block_min_len;
     else if (k == "preprocess_us") *value = (int64_t)h->preprocess_us;
+    else if (k == "pre_d2h_us") *value = (int64_t)h->phase_us[0];
+    else if (k == "pre_colcheck_us") *value = (int64_t)h->phase_us[1];
+    else if (k == "pre_detect_us") *value = (int64_t)h->phase_us[2];
+    else if (k == "pre_table_us") *value = (int64_t)h->phase_us[3];
+    else if (k == "pre_upload_us") *value = (int64_t)h->phase_us[4];
     else if (k == "prepared") *value = h->prepared ? 1 : 0;
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
@@ -236,6 +242,13 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     }
     if (ptr[0] != 0 && (int64_t)ptr[0] > h->nnz) return MI_SPMM_ECSR;
     h->max_row_nnz = max_len;
+    auto lap = [&](int i, std::chrono::steady_clock::time_point &from) {
+        const auto now = std::chrono::steady_clock::now();
+        h->phase_us[i] = std::chrono::duration<double, std::micro>(now - from).count();
+        from = now;
+    };
+    auto tp = t0;
+    lap(0, tp);
 
     // column range: one pass over col_idx on the device (an out-of-range
     // column is an out-of-bounds read of B, i.e. a GPU fault)
@@ -257,6 +270,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         if (bad) return MI_SPMM_ECSR;
     }
 
+    lap(1, tp);
     // block path: 16-row groups with one shared column list (min_len <= L <= split threshold)
     {
         const int32_t N = h->feat;
@@ -285,6 +299,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         }
     }
 
+    lap(2, tp);
     // Segment table (the reference's Task list, spmm_opt.cu:43-54, kept only for rows that need it):
     //   len > long_thr                 -> pieces of long_chunk nonzeros, partial sums + ordered reduce
     //   medium_thr < len <= long_thr   -> ONE segment = the whole row, stored straight to C (exact order)
@@ -301,6 +316,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);
     int32_t n_slots = 0, n_medium = 0;
     if (max_len > mthr) {
+        chunks.reserve(1 << 16);
         for (int32_t r = 0; r < M; ++r) {
             const int32_t beg = ptr[r], end = ptr[r + 1], len = end - beg;
             if (len <= mthr) continue;
@@ -331,8 +347,15 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
             }
             longs.push_back(L);
         }
-        std::stable_sort(chunks.begin(), chunks.end(),
-                         [](const Chunk &x, const Chunk &y) { return (x.end - x.beg) > (y.end - y.beg); });
+        // longest first, stable: counting sort on the length (<= max(long_thr, long_chunk) by construction)
+        int32_t lmax = 0;
+        for (const Chunk &c : chunks) lmax = std::max(lmax, c.end - c.beg);
+        std::vector<int32_t> start((size_t)lmax + 2, 0);
+        for (const Chunk &c : chunks) ++start[(size_t)(lmax - (c.end - c.beg)) + 1];
+        for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+        std::vector<Chunk> sorted(chunks.size());
+        for (const Chunk &c : chunks) sorted[(size_t)start[(size_t)(lmax - (c.end - c.beg))]++] = c;
+        chunks.swap(sorted);
     }
     h->n_chunks = (int32_t)chunks.size();
     h->n_long = (int32_t)longs.size();
@@ -340,6 +363,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     h->n_slots = n_slots;
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)n_medium;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
+    lap(3, tp);
     if (h->n_chunks > 0) {
         const size_t cb = chunks.size() * sizeof(Chunk), lb = longs.size() * sizeof(LongRow);
         const size_t pb = (size_t)n_slots * (size_t)h->ldp * sizeof(float);
@@ -357,6 +381,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         }
         h->ws_bytes = cb + lb + pb;
     }
+    lap(4, tp);
     h->prepared = true;
     h->preprocess_us =
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
