@@ -30,6 +30,7 @@ struct mi_spmm_handle {
     int32_t num_v, num_cols, feat;
     int64_t nnz;
     // options
+    int64_t long_thr_user;  // what the caller asked for (0 = auto); long_thr holds the resolved value
     int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel
     int64_t long_thr, long_chunk, unroll, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
@@ -125,7 +126,8 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->nnz = nnz;
     h->feat = feat_in;
     h->medium_thr = 64;
-    h->long_thr = 2048;    // rows up to here stay ONE exact segment; only hubs are split (profiles/r01_thresholds.txt)
+    h->long_thr = 0;       // 0 = auto, resolved in preprocess: clamp(nnz / 8192, 256, 2048)
+    h->long_thr_user = 0;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->unroll = 8;
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
@@ -165,7 +167,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     if (!good(h) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
     if (k == "medium_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
-    else if (k == "long_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->long_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+    else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
     else if (k == "long_row_chunk") { if (v < 1) return MI_SPMM_EINVAL; h->long_chunk = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "unroll") { if (v != 4 && v != 8 && v != 16) return MI_SPMM_EINVAL; h->unroll = v; }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
@@ -229,6 +231,15 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MI_SPMM_ENODEVICE;
 
     const int32_t M = h->num_v;
+    // Split threshold.  Rows up to it stay ONE exact segment; longer ones (hubs) are cut into pieces so
+    // that no single lane group holds a noticeable share of the work.  auto: 2048 once there is enough
+    // work to hide a 2048-nonzero segment (nnz >= 2^24), proportionally lower for small matrices
+    // (profiles/r01_thresholds.txt).  An explicit value is taken as is.
+    if (h->long_thr_user > 0) h->long_thr = h->long_thr_user;
+    else {
+        int64_t t = h->nnz / 8192;
+        h->long_thr = t < 256 ? 256 : (t > 2048 ? 2048 : t);
+    }
     std::vector<int32_t> ptr((size_t)M + 1);
     HIP_TRY(hipMemcpy(ptr.data(), h->d_ptr, sizeof(int32_t) * ((size_t)M + 1), hipMemcpyDeviceToHost));
     // data.cu:40-45 asserts ptr[num_v] == num_e; we also need monotone rows,

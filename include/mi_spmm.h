@@ -105,7 +105,8 @@ const char *mi_spmm_strerror(int code);
 
 /* Tuning / introspection.  Keys (all int64):
  *   "medium_row_threshold" rows longer than this run as ONE exact segment in the segment kernel
- *   "long_row_threshold"  rows with more nonzeros are split into chunks
+ *   "long_row_threshold"  rows with more nonzeros are split into chunks (0 = auto:
+ *                         clamp(nnz/8192, 256, 2048); get returns the resolved value after preprocess)
  *   "long_row_chunk"      chunk length in nonzeros
  *   "unroll"              B-row loads in flight per lane group (4,8,16)
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)

@@ -121,12 +121,13 @@ def test_power_law_rows(device, oracle):
     vals = synth.normal_f32(idx.size, 6)
     B = synth.normal_f32(20000 * 128, 7).reshape(20000, 128)
     C, op = run_spmm(device, ptr, idx, vals, B)
-    assert op.get_option("long_row_threshold") == 2048 and op.get_option("n_long_rows") > 0
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, 2048, 256)
+    thr = op.get_option("long_row_threshold")          # auto: clamp(nnz / 8192, 256, 2048)
+    assert thr == min(2048, max(256, idx.size // 8192)) and op.get_option("n_long_rows") > 0
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, thr, 256)
     assert np.array_equal(bits(C), bits(exp))
-    C5, op5 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512, "long_row_chunk": 100})
+    C5, op5 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 100, "long_row_chunk": 70})
     assert op5.get_option("n_long_rows") > op.get_option("n_long_rows")
-    assert np.array_equal(bits(C5), bits(oracle.spmm_chunked(ptr, idx, vals, B, 512, 100)))
+    assert np.array_equal(bits(C5), bits(oracle.spmm_chunked(ptr, idx, vals, B, 100, 70)))
     C2, _ = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 1 << 30})
     assert np.array_equal(bits(C2), bits(oracle.spmm_omp(ptr, idx, vals, B)))
 
@@ -282,8 +283,8 @@ def _shared_list_case(n_groups, K, N, seed, lens=None, tail_rows=5):
 def test_block_path_bitwise(device, oracle, N):
     ptr, idx, vals, B, kinds = _shared_list_case(60, 3000, N, seed=300 + N)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
-    C, op = run_spmm(device, ptr, idx, vals, B)
-    expect_groups = sum(1 for k, L in kinds if k == 0 and 8 <= L <= 2048)
+    C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 2048})
+    expect_groups = sum(1 for k, L in kinds if k == 0 and 8 <= L <= op.get_option("long_row_threshold"))
     assert op.get_option("n_block_groups") == expect_groups and expect_groups > 5
     assert not np.isnan(C).any()
     assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).sum()} of {C.size} differ"
@@ -297,7 +298,7 @@ def test_block_path_list_lengths(device, oracle, L):
     """Every tail shape of the k loop (batches of 8/16/32/64 k-rows, MFMA k-steps of 4)."""
     for N in (32, 128, 256):
         ptr, idx, vals, B, kinds = _shared_list_case(9, 700, N, seed=900 + L, lens=[L])
-        C, op = run_spmm(device, ptr, idx, vals, B)
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 2048})
         assert op.get_option("n_block_groups") == sum(1 for k, _ in kinds if k == 0)
         assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (L, N)
 
