@@ -224,7 +224,7 @@ def main():
                             f"N={n_total} fp32 ({n_loc} columns per GPU), int32 indices",
                 "M": M, "K": M, "nnz": nnz, "N": n_total, "cols_per_gpu": n_loc,
                 "parallelism": "single GPU" if world == 1 else f"column-sharded x{world}, RCCL all-gather of C blocks, {args.panels} row panels",
-                "options": {k: op.get_option(k) for k in ("kernel", "unroll", "rows_per_block", "block_threads", "xcd_remap", "nt_store", "nt_stream",
+                "options": {k: op.get_option(k) for k in ("kernel", "rows_per_block", "block_threads", "xcd_remap", "nt_store", "nt_stream",
                                                           "long_row_threshold", "long_row_chunk", "n_long_rows", "n_chunks",
                                                           "lanes_per_row", "vector_width", "n_launches")},
                 "preprocess_ms": round(t_pre * 1e3, 2), "input_gen_s": round(t_gen, 1),
@@ -282,8 +282,7 @@ def sweep(args, op, step, M, N, nnz):
 
     model = synth.bytes_model(M, M, N, nnz)
     grids = {
-        "knobs": dict(unroll=[4, 8, 16], nt_store=[0, 1], nt_stream=[0, 1], xcd_remap=[0, 1], rows_per_block=[0]),
-        "rpb": dict(unroll=[8], nt_store=[1], nt_stream=[1], xcd_remap=[1], rows_per_block=[8, 16, 32, 64, 128, 256, 1024]),
+        "knobs": dict(kernel=[2], nt_store=[0, 1], nt_stream=[0, 1], xcd_remap=[0, 1], rows_per_block=[0]),
         "wide": dict(kernel=[1, 2], nt_store=[1], nt_stream=[0], xcd_remap=[0, 1], rpg=[1, 2, 8]),
         "bt": dict(kernel=[2], nt_store=[1], nt_stream=[0], xcd_remap=[0, 1], block_threads=[64, 128, 256], rpg=[1, 2]),
         "rpg": dict(kernel=[2], nt_store=[1], nt_stream=[0, 1], xcd_remap=[1], rpg=[1, 2, 3, 4, 8, 16]),

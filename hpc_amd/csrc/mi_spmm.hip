@@ -32,7 +32,7 @@ struct mi_spmm_handle {
     // options
     int64_t long_thr_user;  // what the caller asked for (0 = auto); long_thr holds the resolved value
     int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel
-    int64_t long_thr, long_chunk, unroll, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
+    int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
     // plan
@@ -129,7 +129,6 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->long_thr = 0;       // 0 = auto, resolved in preprocess: clamp(nnz / 8192, 256, 2048)
     h->long_thr_user = 0;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
-    h->unroll = 8;
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
     h->xcd_remap = -1;     // auto (see run)
     h->nt_store = 1;       // C is write-once
@@ -169,7 +168,6 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     if (k == "medium_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
     else if (k == "long_row_chunk") { if (v < 1) return MI_SPMM_EINVAL; h->long_chunk = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
-    else if (k == "unroll") { if (v != 4 && v != 8 && v != 16) return MI_SPMM_EINVAL; h->unroll = v; }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
     else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
@@ -191,7 +189,6 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_medium_rows") *value = h->n_medium;
     else if (k == "n_partial_slots") *value = h->n_slots;
     else if (k == "long_row_chunk") *value = h->long_chunk;
-    else if (k == "unroll") *value = h->unroll;
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
     else if (k == "kernel") *value = h->kernel;
@@ -404,43 +401,26 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
 // ---- launch dispatch ------------------------------------------------------------
 namespace {
 
-// Tunable matrix (unroll x cache policy) is instantiated for the 16-byte narrow
-// path, which is what every benchmark shape uses; the dword and wide-address
-// fallbacks get one configuration each.
-template <int V, int LPR, int U, bool WIDE, int POL>
-void launch_rows_k(const RowsArgs &a, dim3 grid, hipStream_t s)
-{
-    hipLaunchKernelGGL((spmm_rows<V, LPR, (U > LPR ? LPR : U), WIDE, POL>), grid, dim3(kBlockThreads), 0, s, a);
-}
-template <int LPR, int U>
-void launch_rows_pol(int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
-{
-    switch (pol & 3) {
-    case 0: launch_rows_k<4, LPR, U, false, 0>(a, grid, s); break;
-    case 1: launch_rows_k<4, LPR, U, false, 1>(a, grid, s); break;
-    case 2: launch_rows_k<4, LPR, U, false, 2>(a, grid, s); break;
-    default: launch_rows_k<4, LPR, U, false, 3>(a, grid, s); break;
-    }
-}
-template <int LPR>
-void launch_rows_tuned(int unroll, int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
-{
-    switch (unroll) {
-    case 1: case 2: case 4: launch_rows_pol<LPR, 4>(pol, a, grid, s); break;
-    case 16: launch_rows_pol<LPR, 16>(pol, a, grid, s); break;
-    default: launch_rows_pol<LPR, 8>(pol, a, grid, s); break;
-    }
-}
+// v1 rows kernel (per-row fetch, no prefetch): kept as the A/B baseline only, one configuration per shape.
 template <int V, bool WIDE>
-void launch_rows_fixed(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
+void launch_rows_v1(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
 {
     switch (lpr) {
-    case 8: launch_rows_k<V, 8, 8, WIDE, 3>(a, grid, s); break;
-    case 16: launch_rows_k<V, 16, 8, WIDE, 3>(a, grid, s); break;
-    case 32: launch_rows_k<V, 32, 8, WIDE, 3>(a, grid, s); break;
-    default: launch_rows_k<V, 64, 8, WIDE, 3>(a, grid, s); break;
+    case 8: hipLaunchKernelGGL((spmm_rows<V, 8, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((spmm_rows<V, 16, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((spmm_rows<V, 32, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((spmm_rows<V, 64, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
     }
 }
+void launch_rows_any(bool vec4, bool wide, int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
+{
+    if (vec4) { if (wide) launch_rows_v1<4, true>(lpr, a, grid, s); else launch_rows_v1<4, false>(lpr, a, grid, s); }
+    else { if (wide) launch_rows_v1<1, true>(lpr, a, grid, s); else launch_rows_v1<1, false>(lpr, a, grid, s); }
+}
+
+// v2 rows kernel: the cache policy (nt C stores x nt (col,val) loads) and the workgroup size are
+// instantiated for the 16-byte narrow path, which every benchmark shape uses; the dword and
+// wide-address fallbacks get the default policy.
 template <int LPR, int BT>
 void launch_rows_v2_pol(int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
 {
@@ -480,20 +460,6 @@ void launch_rows_v2_any(bool vec4, bool wide, int lpr, int bt, int pol, const Ro
     } else if (vec4) launch_rows_v2_fixed<4, true>(lpr, a, grid, s);
     else if (wide) launch_rows_v2_fixed<1, true>(lpr, a, grid, s);
     else launch_rows_v2_fixed<1, false>(lpr, a, grid, s);
-}
-
-void launch_rows_any(bool vec4, bool wide, int lpr, int unroll, int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
-{
-    if (vec4 && !wide) {
-        switch (lpr) {
-        case 8: launch_rows_tuned<8>(unroll, pol, a, grid, s); break;
-        case 16: launch_rows_tuned<16>(unroll, pol, a, grid, s); break;
-        case 32: launch_rows_tuned<32>(unroll, pol, a, grid, s); break;
-        default: launch_rows_tuned<64>(unroll, pol, a, grid, s); break;
-        }
-    } else if (vec4) launch_rows_fixed<4, true>(lpr, a, grid, s);
-    else if (wide) launch_rows_fixed<1, true>(lpr, a, grid, s);
-    else launch_rows_fixed<1, false>(lpr, a, grid, s);
 }
 
 template <int V, int LPR, bool WIDE>
@@ -651,7 +617,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     const bool rows_needed = !(blocks_on && h->n_rows_for_rows_kernel == 0);
     if (!rows_needed) { /* skip */ }
     else if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
-    else launch_rows_any(vec4, wide, lpr, (int)h->unroll, pol, a, grid, s);
+    else launch_rows_any(vec4, wide, lpr, a, grid, s);
     if (rows_needed) ++launches;
 
     if (h->n_long > 0 && do_long) {

@@ -108,7 +108,6 @@ const char *mi_spmm_strerror(int code);
  *   "long_row_threshold"  rows with more nonzeros are split into chunks (0 = auto:
  *                         clamp(nnz/8192, 256, 2048); get returns the resolved value after preprocess)
  *   "long_row_chunk"      chunk length in nonzeros
- *   "unroll"              B-row loads in flight per lane group (4,8,16)
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto

@@ -51,11 +51,11 @@ def test_argument_checks_without_a_gpu():
     assert lib.mi_spmm_create(ctypes.byref(h), dummy, None, None, 4, 4, 3, 8) == -1          # nnz>0, NULL idx
     assert lib.mi_spmm_create(ctypes.byref(h), dummy, None, None, 4, 4, 0, 8) == 0
     assert lib.mi_spmm_run(h, None, None, None) == -3                                         # run before preprocess
-    assert lib.mi_spmm_set_option(h, b"unroll", 3) == -1
+    assert lib.mi_spmm_set_option(h, b"block_threads", 100) == -1
     assert lib.mi_spmm_set_option(h, b"no_such_key", 1) == -5
-    assert lib.mi_spmm_set_option(h, b"unroll", 16) == 0
+    assert lib.mi_spmm_set_option(h, b"block_threads", 128) == 0
     v = ctypes.c_int64(0)
-    assert lib.mi_spmm_get_option(h, b"unroll", ctypes.byref(v)) == 0 and v.value == 16
+    assert lib.mi_spmm_get_option(h, b"block_threads", ctypes.byref(v)) == 0 and v.value == 128
     assert lib.mi_spmm_destroy(h) == 0
     assert lib.mi_spmm_destroy(None) == 0
 

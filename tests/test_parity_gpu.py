@@ -41,15 +41,15 @@ def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
         assert op.get_option("vector_width") == (4 if N % 4 == 0 else 1)
 
 
-@pytest.mark.parametrize("unroll", [4, 8, 16])
+@pytest.mark.parametrize("block_threads", [64, 128, 256])
 @pytest.mark.parametrize("pol", [0, 1, 2, 3])
 @pytest.mark.parametrize("N", [32, 128, 256])
-def test_bitwise_over_tuning_knobs(device, oracle, unroll, pol, N):
+def test_bitwise_over_tuning_knobs(device, oracle, block_threads, pol, N):
     ptr, idx, vals, B = _rand_case(2000, 2000, N, 0, 90, seed=7)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
     for rpb, xcd, kernel in ((0, 1, 1), (16, 0, 1), (1000, 1, 1), (0, 1, 2), (8, 0, 2), (1000, 0, 2)):
         C, _ = run_spmm(device, ptr, idx, vals, B, options={
-            "unroll": unroll, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd,
+            "block_threads": block_threads, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd,
             "kernel": kernel})
         assert np.array_equal(bits(C), bits(ref)), (rpb, xcd, kernel)
 
