@@ -259,7 +259,7 @@ def cpu_baseline(args, ptr, idx, vals, B, M, N):
     t = time.perf_counter()
     oracle.spmm_omp(sub_ptr, idx, vals, B, out=out)          # warm-up (and first-touch of out)
     first = time.perf_counter() - t
-    reps = 3 if first < 8 else 1
+    reps = 5 if first < 4 else (3 if first < 8 else 1)
     times = []
     for _ in range(reps):
         t = time.perf_counter()

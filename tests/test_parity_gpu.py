@@ -538,3 +538,31 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
         exp = oracle.spmm_chunked(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["long_row_threshold"], opts["long_row_chunk"])
         assert np.array_equal(bits(got[:, :N]), bits(exp)), (case, M, K, N, ldb, ldc, opts)
         assert np.isnan(got[:, N:]).all(), "wrote outside its N columns"
+
+
+def test_special_values_all_paths(device, oracle):
+    """inf, NaN, -0.0 and subnormals in A and B through the rows, segment (medium + split) and MFMA block
+    paths: same bits as the oracle (NaNs compared as NaN: payloads are not part of the contract).
+    Guards the kernels' padding trick (empty slots are fma(+0, +0, acc)) and the f32 MFMA's subnormal handling."""
+    g = np.random.Generator(np.random.Philox(key=[77, 7]))
+    ptr, idx, vals, B, kinds = _shared_list_case(24, 1500, 128, seed=4242)      # block groups + ragged rows
+    # add some long rows at the end
+    extra = [np.sort(g.choice(1500, d, replace=False)).astype(np.int32) for d in (700, 90, 300)]
+    idx = np.concatenate([idx] + extra)
+    ptr = np.concatenate([ptr, ptr[-1] + np.cumsum([e.size for e in extra])]).astype(np.int32)
+    vals = synth.normal_f32(idx.size, 1)
+    B = synth.normal_f32(1500 * 128, 2).reshape(1500, 128)
+    special = np.array([np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-40, -3e-42, 1.1754942e-38, 3.4e38, -3.4e38], np.float32)
+    vals[g.integers(0, vals.size, 400)] = special[g.integers(0, special.size, 400)]
+    B.reshape(-1)[g.integers(0, B.size, 4000)] = special[g.integers(0, special.size, 4000)]
+    ref = oracle.spmm_chunked(ptr, idx, vals, B, 256, 64)
+    for opts in ({"kernel": 2}, {"kernel": 1}, {"block_path": 0}):
+        o = {"long_row_threshold": 256, "long_row_chunk": 64}
+        o.update(opts)
+        C, op = run_spmm(device, ptr, idx, vals, B, options=o)
+        both_nan = np.isnan(C) & np.isnan(ref)
+        same = (bits(C) == bits(ref)) | both_nan
+        assert same.all(), (opts, int((~same).sum()))
+        assert np.isnan(ref).any() and np.isinf(ref).any()
+        if "block_path" not in opts:
+            assert op.get_option("n_block_groups") > 0 and op.get_option("n_long_rows") > 0 and op.get_option("n_medium_rows") > 0
