@@ -7,6 +7,7 @@
 //   run:        rows kernel (+ chunks + reduce when long rows exist) on the
 //               caller's stream; overwrite semantics; no host sync.
 #include "../../include/mi_spmm.h"
+#include "plan.hpp"
 #include "spmm_kernels.hpp"
 
 #include <algorithm>
@@ -34,6 +35,7 @@ struct mi_spmm_handle {
     int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel
     int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
+    int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
     // plan
     bool prepared;
@@ -75,6 +77,71 @@ static void free_plan(mi_spmm_handle *h)
     h->n_chunks = h->n_long = h->n_medium = h->n_slots = 0;
     h->ws_bytes = 0;
     h->prepared = false;
+}
+
+static bool block_path_shape_ok(int32_t N) { return N == 32 || N == 64 || N == 128 || (N >= 256 && N % 256 == 0); }
+
+// preprocess with no host pass over the rows: column check, block detection, classification, scans,
+// segment emission and the length sort all run on the device; one small copy comes back.
+static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_point t0)
+{
+    const int32_t M = h->num_v;
+    auto tp = t0;
+    auto lap = [&](int i) {
+        const auto now = std::chrono::steady_clock::now();
+        h->phase_us[i] = std::chrono::duration<double, std::micro>(now - tp).count();
+        tp = now;
+    };
+    lap(0);
+    unsigned int *d_bad = nullptr;
+    if (h->nnz > 0) {
+        HIP_TRY(hipMalloc((void **)&d_bad, 256));
+        hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), 0);
+        if (e == hipSuccess) {
+            const int64_t want = (h->nnz + kBlockThreads * 8 - 1) / (kBlockThreads * 8);
+            const int grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+            hipLaunchKernelGGL(csr_check_cols, dim3(grid), dim3(kBlockThreads), 0, 0, h->d_idx, h->nnz, h->num_cols, d_bad);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) { (void)hipFree(d_bad); return (int)e; }
+    }
+    lap(1);
+    if (h->block_path && block_path_shape_ok(h->feat) && M >= 16 && h->nnz > 0) {
+        const int32_t n_groups = (M + 15) / 16;
+        if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) { if (d_bad) (void)hipFree(d_bad); return MI_SPMM_ENOMEM; }
+        hipLaunchKernelGGL(detect_row_blocks, dim3((n_groups + 3) / 4), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M,
+                           (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
+    }
+    lap(2);
+    PlanOut po;
+    const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);
+    const int rc = build_plan_gpu(h->d_ptr, M, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
+                                  (int32_t)h->long_chunk, &po);
+    if (d_bad) (void)hipFree(d_bad);
+    h->d_chunks = po.d_chunks;
+    h->d_long = po.d_long;
+    h->d_blk_groups = po.d_blk_groups;
+    if (rc != 0) { free_plan(h); return rc; }
+    h->n_chunks = po.n_chunks;
+    h->n_long = po.n_long;
+    h->n_slots = po.n_slots;
+    h->n_medium = po.n_medium;
+    h->n_blk_groups = po.n_blk_groups;
+    h->max_row_nnz = po.max_len;
+    if (h->n_blk_groups == 0 && h->d_blk_flag) { (void)hipFree(h->d_blk_flag); h->d_blk_flag = nullptr; }
+    h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)h->n_medium;
+    h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
+    lap(3);
+    if (h->n_slots > 0) {
+        const size_t pb = (size_t)h->n_slots * (size_t)h->ldp * sizeof(float);
+        if (hipMalloc((void **)&h->d_partials, pb) != hipSuccess) { free_plan(h); return MI_SPMM_ENOMEM; }
+        h->ws_bytes = pb;
+    }
+    h->ws_bytes += (size_t)h->n_chunks * sizeof(Chunk) + (size_t)h->n_long * sizeof(LongRow);
+    lap(4);
+    h->prepared = true;
+    h->preprocess_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return MI_SPMM_OK;
 }
 
 extern "C" {
@@ -136,6 +203,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->block_path = 1;
     h->block_min_len = 8;
     h->kernel = 2;
+    h->gpu_preprocess = 1;
     h->block_threads = 256;
     *out = h;
     return MI_SPMM_OK;
@@ -171,6 +239,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
     else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
+    else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
@@ -192,6 +261,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
     else if (k == "kernel") *value = h->kernel;
+    else if (k == "gpu_preprocess") *value = h->gpu_preprocess;
     else if (k == "block_threads") *value = h->block_threads;
     else if (k == "nt_store") *value = h->nt_store;
     else if (k == "nt_stream") *value = h->nt_stream;
@@ -237,6 +307,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         int64_t t = h->nnz / 8192;
         h->long_thr = t < 256 ? 256 : (t > 2048 ? 2048 : t);
     }
+    if (h->gpu_preprocess) return preprocess_on_gpu(h, t0);
     std::vector<int32_t> ptr((size_t)M + 1);
     HIP_TRY(hipMemcpy(ptr.data(), h->d_ptr, sizeof(int32_t) * ((size_t)M + 1), hipMemcpyDeviceToHost));
     // data.cu:40-45 asserts ptr[num_v] == num_e; we also need monotone rows,
@@ -282,7 +353,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     // block path: 16-row groups with one shared column list (min_len <= L <= split threshold)
     {
         const int32_t N = h->feat;
-        const bool n_ok = (N == 32 || N == 64 || N == 128 || (N >= 256 && N % 256 == 0));
+        const bool n_ok = block_path_shape_ok(N);
         if (h->block_path && n_ok && M >= 16 && h->nnz > 0) {
             const int32_t n_groups = (M + 15) / 16;
             if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;

@@ -1,0 +1,26 @@
+// plan.hpp -- what preprocess produces for run(): the segment table (medium rows + pieces of split
+// rows, longest first), the split-row table, the compacted list of block-path groups.  Built either
+// on the GPU (preprocess_gpu.hip, default) or by the reference-style host loop (mi_spmm.hip,
+// "gpu_preprocess" = 0, kept as the cross-check).  Internal to libmi_spmm.so.
+#pragma once
+#include <stdint.h>
+
+#include "plan_types.hpp"
+
+namespace mi {
+
+struct PlanOut {
+    Chunk *d_chunks = nullptr;      // [n_chunks], sorted by length descending (stable in row order)
+    LongRow *d_long = nullptr;      // [n_long]
+    int32_t *d_blk_groups = nullptr;  // [n_blk_groups] (only when d_blk_flag was given)
+    int32_t n_chunks = 0, n_long = 0, n_slots = 0, n_medium = 0, n_blk_groups = 0;
+    int32_t max_len = 0;
+};
+
+// Returns 0, a negative MI_SPMM_E* code (malformed CSR, out of memory) or a positive hipError_t.
+// d_blk_flag: per 16-row group, 1 = block path owns it (nullable).  col_bad: device flag written
+// by csr_check_cols earlier on the same (null) stream; read back with the same single copy.
+int build_plan_gpu(const int32_t *d_row_ptr, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
+                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out);
+
+}  // namespace mi

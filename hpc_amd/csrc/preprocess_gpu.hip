@@ -1,0 +1,204 @@
+// preprocess_gpu.hip -- the segment table built on the device.
+//
+// The reference builds its Task list with a single-threaded host loop over row_ptr after a D2H copy
+// (PA4/workspace/src/spmm_opt.cu:38-62).  Here: one classify kernel over the rows, three exclusive
+// scans (hipCUB), one emit kernel, one stable radix sort by segment length, one flagged select for the
+// block-path groups -- and a single 48-byte copy back to size the allocations.
+#include "plan.hpp"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "../../include/mi_spmm.h"
+
+namespace mi {
+
+struct PlanStats {
+    int32_t max_len;
+    uint32_t bad;      // bit0: negative row length, bit1: ptr[0] < 0
+    int32_t ptr0, ptrM;
+    int32_t n_groups_selected;
+    int32_t pad[3];
+};
+
+__global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__restrict__ row_ptr, int32_t M,
+                                                              const uint8_t *__restrict__ blk_flag, int32_t mthr,
+                                                              int32_t thr, int32_t clen, int32_t *__restrict__ seg_cnt,
+                                                              int32_t *__restrict__ slot_cnt,
+                                                              int32_t *__restrict__ long_cnt, PlanStats *stats)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    int len = 0;
+    unsigned bad = 0;
+    if (r < M) {
+        const int beg = row_ptr[r], end = row_ptr[r + 1];
+        len = end - beg;
+        if (len < 0) { bad = 1; len = 0; }
+        int segs = 0, slots = 0, lng = 0;
+        if (len > mthr) {
+            if (len <= thr) {
+                if (!(blk_flag && blk_flag[r >> 4])) segs = 1;   // medium row: one exact segment
+            } else {
+                segs = slots = (len + clen - 1) / clen;          // hub: pieces + partial-sum slots
+                lng = 1;
+            }
+        }
+        seg_cnt[r] = segs;
+        slot_cnt[r] = slots;
+        long_cnt[r] = lng;
+        if (r == 0) { stats->ptr0 = beg; if (beg < 0) bad |= 2; }
+        if (r == M - 1) stats->ptrM = end;
+    } else if (r == M) {   // trailing zero so the exclusive scans leave the totals at index M
+        seg_cnt[r] = 0;
+        slot_cnt[r] = 0;
+        long_cnt[r] = 0;
+    }
+    // wave-level reduction, one atomic per wave
+    int m = len;
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&stats->max_len, m);
+    if (bad) atomicOr(&stats->bad, bad);   // malformed input only
+}
+
+__global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__restrict__ row_ptr, int32_t M,
+                                                              int32_t thr, int32_t clen,
+                                                              const int32_t *__restrict__ seg_cnt,
+                                                              const int32_t *__restrict__ seg_off,
+                                                              const int32_t *__restrict__ slot_off,
+                                                              const int32_t *__restrict__ long_off,
+                                                              Chunk *__restrict__ chunks, uint32_t *__restrict__ keys,
+                                                              LongRow *__restrict__ longs)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (r >= M) return;
+    const int n = seg_cnt[r];
+    if (n == 0) return;
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    int o = seg_off[r];
+    if (end - beg <= thr) {
+        Chunk c;
+        c.beg = beg;
+        c.end = end;
+        c.slot = -1;
+        c.row = (int32_t)r;
+        chunks[o] = c;
+        keys[o] = (uint32_t)(end - beg);
+        return;
+    }
+    int slot = slot_off[r];
+    LongRow L;
+    L.row = (int32_t)r;
+    L.first_slot = slot;
+    L.n_chunks = n;
+    L.pad = 0;
+    longs[long_off[r]] = L;
+    for (int b = beg; b < end; b += clen, ++o, ++slot) {
+        Chunk c;
+        c.beg = b;
+        c.end = (end - b > clen) ? b + clen : end;
+        c.slot = slot;
+        c.row = (int32_t)r;
+        chunks[o] = c;
+        keys[o] = (uint32_t)(c.end - c.beg);
+    }
+}
+
+namespace {
+struct DevBuf {   // frees on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+}  // namespace
+
+#define PLAN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (e_ == hipErrorOutOfMemory) ? MI_SPMM_ENOMEM : (int)e_; } while (0)
+
+int build_plan_gpu(const int32_t *d_row_ptr, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
+                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out)
+{
+    *out = PlanOut();
+    if (M <= 0) return (nnz == 0) ? MI_SPMM_OK : MI_SPMM_ECSR;
+    const size_t n1 = (size_t)M + 1;
+    DevBuf cnt, off, stats, tmp, groups, ngroups;
+    PLAN_TRY(cnt.alloc(3 * n1 * sizeof(int32_t)));
+    PLAN_TRY(off.alloc(3 * n1 * sizeof(int32_t)));
+    PLAN_TRY(stats.alloc(sizeof(PlanStats)));
+    PLAN_TRY(hipMemsetAsync(stats.p, 0, sizeof(PlanStats), 0));
+    int32_t *seg_cnt = cnt.as<int32_t>(), *slot_cnt = seg_cnt + n1, *long_cnt = slot_cnt + n1;
+    int32_t *seg_off = off.as<int32_t>(), *slot_off = seg_off + n1, *long_off = slot_off + n1;
+    const unsigned grid = (unsigned)((n1 + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr, thr, clen,
+                       seg_cnt, slot_cnt, long_cnt, stats.as<PlanStats>());
+    PLAN_TRY(hipGetLastError());
+    size_t tb = 0, tb2 = 0;
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, seg_cnt, seg_off, (int)n1));
+    const int n_groups_all = (M + 15) / 16;
+    if (d_blk_flag) {
+        PLAN_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb2, hipcub::CountingInputIterator<int32_t>(0), d_blk_flag,
+                                               (int32_t *)nullptr, (int32_t *)nullptr, n_groups_all));
+        PLAN_TRY(groups.alloc((size_t)n_groups_all * sizeof(int32_t)));
+    }
+    PLAN_TRY(tmp.alloc(tb > tb2 ? tb : tb2));
+    size_t t = tb;
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, seg_cnt, seg_off, (int)n1));
+    t = tb;
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, slot_cnt, slot_off, (int)n1));
+    t = tb;
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, long_cnt, long_off, (int)n1));
+    if (d_blk_flag) {
+        t = tb2;
+        PLAN_TRY(hipcub::DeviceSelect::Flagged(tmp.p, t, hipcub::CountingInputIterator<int32_t>(0), d_blk_flag,
+                                               groups.as<int32_t>(), &stats.as<PlanStats>()->n_groups_selected,
+                                               n_groups_all));
+    }
+    // the one copy back: totals (element M of each scan), stats, and the column-check flag
+    struct { int32_t n_chunks, n_slots, n_long; PlanStats st; unsigned int col_bad; } host;
+    host.col_bad = 0;
+    PLAN_TRY(hipMemcpyAsync(&host.n_chunks, seg_off + M, sizeof(int32_t), hipMemcpyDeviceToHost, 0));
+    PLAN_TRY(hipMemcpyAsync(&host.n_slots, slot_off + M, sizeof(int32_t), hipMemcpyDeviceToHost, 0));
+    PLAN_TRY(hipMemcpyAsync(&host.n_long, long_off + M, sizeof(int32_t), hipMemcpyDeviceToHost, 0));
+    PLAN_TRY(hipMemcpyAsync(&host.st, stats.p, sizeof(PlanStats), hipMemcpyDeviceToHost, 0));
+    if (d_col_bad) PLAN_TRY(hipMemcpyAsync(&host.col_bad, d_col_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, 0));
+    PLAN_TRY(hipStreamSynchronize(0));
+    // data.cu:40-45 asserts ptr[num_v] == num_e; monotone rows and in-range columns keep the kernels in bounds
+    if (host.st.bad || host.col_bad || (int64_t)host.st.ptrM != nnz || host.st.ptr0 < 0) return MI_SPMM_ECSR;
+    out->max_len = host.st.max_len;
+    out->n_chunks = host.n_chunks;
+    out->n_slots = host.n_slots;
+    out->n_long = host.n_long;
+    out->n_medium = host.n_chunks - host.n_slots;
+    if (d_blk_flag && host.st.n_groups_selected > 0) {
+        out->n_blk_groups = host.st.n_groups_selected;
+        PLAN_TRY(hipMalloc((void **)&out->d_blk_groups, (size_t)out->n_blk_groups * sizeof(int32_t)));
+        PLAN_TRY(hipMemcpyAsync(out->d_blk_groups, groups.p, (size_t)out->n_blk_groups * sizeof(int32_t),
+                                hipMemcpyDeviceToDevice, 0));
+    }
+    if (host.n_chunks > 0) {
+        DevBuf unsorted, keys_in, keys_out, tmp2;
+        const size_t n = (size_t)host.n_chunks;
+        PLAN_TRY(unsorted.alloc(n * sizeof(Chunk)));
+        PLAN_TRY(keys_in.alloc(n * sizeof(uint32_t)));
+        PLAN_TRY(keys_out.alloc(n * sizeof(uint32_t)));
+        PLAN_TRY(hipMalloc((void **)&out->d_chunks, n * sizeof(Chunk)));
+        PLAN_TRY(hipMalloc((void **)&out->d_long, (host.n_long > 0 ? (size_t)host.n_long : 1) * sizeof(LongRow)));
+        hipLaunchKernelGGL(emit_segments, dim3((unsigned)(((size_t)M + kBlockThreads - 1) / kBlockThreads)),
+                           dim3(kBlockThreads), 0, 0, d_row_ptr, M, thr, clen, seg_cnt, seg_off, slot_off, long_off,
+                           unsorted.as<Chunk>(), keys_in.as<uint32_t>(), out->d_long);
+        PLAN_TRY(hipGetLastError());
+        int end_bit = 1;
+        while (end_bit < 32 && (host.st.max_len >> end_bit)) ++end_bit;
+        size_t sb = 0;
+        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(),
+                                                              unsorted.as<Chunk>(), out->d_chunks, (int)n, 0, end_bit));
+        PLAN_TRY(tmp2.alloc(sb));
+        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2.p, sb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(),
+                                                              unsorted.as<Chunk>(), out->d_chunks, (int)n, 0, end_bit));
+        PLAN_TRY(hipStreamSynchronize(0));   // temporaries die at scope exit
+    } else {
+        PLAN_TRY(hipStreamSynchronize(0));
+    }
+    return MI_SPMM_OK;
+}
+
+}  // namespace mi

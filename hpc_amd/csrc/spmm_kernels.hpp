@@ -17,11 +17,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "plan_types.hpp"
+
 namespace mi {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
-
-constexpr int kBlockThreads = 256;  // 4 waves; 8 such blocks fill a CU's 32 wave slots
 
 struct RowsArgs {
     const int32_t *row_ptr;
@@ -39,21 +39,6 @@ struct RowsArgs {
     int32_t nblk;           // gridDim.x (for the XCD remap)
     int32_t flags;          // kFlagXcdRemap
     const uint8_t *blk_flag; // per 16-row group: 1 = owned by the block (MFMA) path; may be null
-};
-
-struct Chunk {              // one segment of one row, handled by one lane group
-    int32_t beg;            // first nonzero (index into col_idx/vals)
-    int32_t end;            // one past the last
-    int32_t slot;           // >= 0: row of the partial-sum workspace it writes (piece of a split row)
-                            //  < 0: the segment is the WHOLE row -> result goes straight to C[row]
-    int32_t row;            // CSR row it belongs to
-};
-
-struct LongRow {
-    int32_t row;
-    int32_t first_slot;
-    int32_t n_chunks;
-    int32_t pad;
 };
 
 enum : int32_t { kFlagXcdRemap = 4 };

@@ -190,7 +190,8 @@ def test_validator_matches_reference_rules(device, oracle):
         assert oracle.ref_valid(d_a, d_b, a.size) == oracle.valid_int(a, b)
 
 
-def test_malformed_csr_is_rejected_not_faulted(device):
+@pytest.mark.parametrize("gpu_pre", [1, 0])
+def test_malformed_csr_is_rejected_not_faulted(device, gpu_pre):
     import torch
     from hpc_amd import CSR, SpMMOpt, MiSpmmError
 
@@ -207,6 +208,7 @@ def test_malformed_csr_is_rejected_not_faulted(device):
     for why, (ptr, idx) in bad_cases.items():
         d_ptr, d_idx = to_dev(device, ptr, idx)
         op = SpMMOpt(CSR(M, 4, d_ptr, d_idx, val), N)
+        op.set_option("gpu_preprocess", gpu_pre)
         with pytest.raises(MiSpmmError) as e:
             op.preprocess(B, Cc)
         assert e.value.code == -4, why
@@ -566,3 +568,31 @@ def test_special_values_all_paths(device, oracle):
         assert np.isnan(ref).any() and np.isinf(ref).any()
         if "block_path" not in opts:
             assert op.get_option("n_block_groups") > 0 and op.get_option("n_long_rows") > 0 and op.get_option("n_medium_rows") > 0
+
+
+def test_gpu_and_host_plan_builders_agree(device, oracle):
+    """the segment table built on the device (classify + scans + emit + radix sort) against
+    the reference-style host loop: same counts, same results, on hub-heavy, block and mixed structures."""
+    cases = {
+        "rmat": synth.csr_rmat(15, 24, seed=4),
+        "powerlaw": synth.csr_powerlaw(30000, 40.0, 3000, seed=4),
+        "uniform": synth.csr_uniform(5000, 0, 50, seed=4),
+        "blocks": _shared_list_case(50, 2500, 128, seed=44)[:2],
+        "single_row": (np.array([0, 5000], np.int32), np.arange(5000, dtype=np.int32)),
+    }
+    for name, (ptr, idx) in cases.items():
+        M = ptr.size - 1
+        K = max(M, int(idx.max()) + 1 if idx.size else 1)
+        vals = synth.normal_f32(idx.size, 8)
+        B = synth.normal_f32(K * 128, 9).reshape(K, 128)
+        for thr in (0, 100):                                   # auto and a low explicit threshold
+            res = {}
+            for gpu_pre in (1, 0):
+                C, op = run_spmm(device, ptr, idx, vals, B, options={"gpu_preprocess": gpu_pre, "long_row_threshold": thr,
+                                                                    "long_row_chunk": 64})
+                res[gpu_pre] = (C, {k: op.get_option(k) for k in ("n_chunks", "n_long_rows", "n_medium_rows", "n_partial_slots",
+                                                                  "n_block_groups", "max_row_nnz", "long_row_threshold")})
+            assert res[1][1] == res[0][1], (name, thr, res[1][1], res[0][1])
+            assert np.array_equal(bits(res[1][0]), bits(res[0][0])), (name, thr)
+            t = res[1][1]["long_row_threshold"]
+            assert np.array_equal(bits(res[1][0]), bits(oracle.spmm_chunked(ptr, idx, vals, B, t, 64))), (name, thr)
