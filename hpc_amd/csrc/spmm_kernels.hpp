@@ -8,11 +8,17 @@
 //
 // Arithmetic contract (include/mi_spmm.h): every output element is the fp32
 // fma chain over the row's nonzeros in stored order starting from +0.0f --
-// exactly spmm_ref.cu:10-14 under the reference's fmad build.  The "rows"
-// kernel keeps that order (no cross-lane reduction at all: a lane owns its
-// output columns), so it is bit-identical to the oracle.  Only rows longer
-// than the split threshold go through "chunks" + "reduce", which sum
-// per-chunk chains in chunk order (deterministic, not bit-identical).
+// exactly spmm_ref.cu:10-14 under the reference's fmad build.
+//
+//   spmm_rows_v2     short rows; a lane group per row, lanes own output columns, no cross-lane
+//                    reduction -> bit-identical to the reference kernel   
+//   spmm_rows        the first version of the same (per-row fetch, no prefetch): A/B baseline
+//   spmm_chunks      medium rows as ONE exact segment each (straight to C) and hub rows as pieces
+//   spmm_reduce_chunks   ... whose partial sums are added left to right (deterministic; the only
+//                    place where the summation order differs from the reference)   (4.2)
+//   detect_row_blocks + spmm_blocks   16-row groups sharing a column list: B rows staged once per
+//                    group through wave-private LDS, v_mfma_f32_16x16x4_f32 (exact f32) (4.3)
+//   csr_check_cols, compare_kernel (valid.cu), fill_normal_kernel (data.h allocate), unpack_gathered
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
