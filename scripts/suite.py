@@ -60,7 +60,7 @@ def main():
         "banded": lambda: synth.csr_banded(M),
         "denseish": lambda: synth.csr_uniform(M // 4, 300, 700),
     }
-    plan = [("uniform32", [32, 64, 128, 256, 512, 1024]), ("powerlaw32", [32, 128, 256]), ("blockdense", [128, 256]),
+    plan = [("uniform32", [32, 64, 128, 256, 512, 1024]), ("powerlaw32", [32, 128, 256]), ("blockdense", [32, 64, 128, 256, 512]),
             ("rmat", [32, 128, 256]), ("banded", [32, 128, 256]), ("denseish", [32, 128, 256])]
     if args.quick:
         plan = [("uniform32", [32, 128, 256]), ("powerlaw32", [128]), ("blockdense", [256])]
