@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the workload the CPU baseline runs (default: all for C1)")
     ap.add_argument("--check", action="store_true", help="verify a row sample against the oracle after timing")
     ap.add_argument("--sweep", default=None, help="tuning sweep name: knobs")
+    ap.add_argument("--rehearse-multi", action="store_true",
+                    help="run the N>1 code path (RCCL group, panel pipeline, breakdown legs) with a world of 1 on one GPU")
     return ap.parse_args()
 
 
@@ -121,9 +123,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or args.rehearse_multi
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" IS RCCL on ROCm
 
     from hpc_amd import CSR, SpMMOpt, synth
     from hpc_amd.dist import ColumnShardedSpMM, ShardLayout
@@ -135,7 +139,7 @@ def main():
     t_gen = time.time() - t_gen
     d_ptr, d_idx, d_val, d_B = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals, B_loc))
     d_Cfull = torch.full((M, n_total), float("nan"), dtype=torch.float32, device=dev)
-    d_Cloc = d_Cfull if world == 1 else torch.empty((M, n_loc), dtype=torch.float32, device=dev)
+    d_Cloc = d_Cfull if not multi else torch.empty((M, n_loc), dtype=torch.float32, device=dev)
 
     op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), n_loc)
     for kv in args.opt:
@@ -150,16 +154,17 @@ def main():
     torch.cuda.synchronize()
     t_pre = time.time() - t_pre
 
-    sharded = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), unpack_gathered, n_panels=args.panels)
+    sharded = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), unpack_gathered, n_panels=args.panels,
+                                force_collective=args.rehearse_multi)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     def step():
         sharded.run(d_B, d_Cloc, d_Cfull)
 
-    if args.sweep and world == 1:
+    if args.sweep and not multi:
         sweep(args, op, step, M, n_loc, nnz)
         return
 
@@ -178,7 +183,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -189,7 +194,7 @@ def main():
     model = synth.bytes_model(M, M, n_loc, nnz)          # per launch = per GPU
     flops_total = 2.0 * nnz * n_total
     value = flops_total / (ms_per_step * 1e-3) / 1e9 if args.steps else float("nan")
-    achieved = model["bytes_alg"] / (dev_ms_mean * 1e-3) / 1e9 if world == 1 else None
+    achieved = model["bytes_alg"] / (dev_ms_mean * 1e-3) / 1e9 if not multi else None
 
     check = None
     if args.check:
@@ -209,7 +214,8 @@ def main():
     # N > 1: compute-only and exchange-only legs, outside the timed region (report
     # compute scaling and end-to-end scaling separately; the step is bound by the all-gather)
     breakdown = None
-    if world > 1:
+    if multi:
+      try:
         def timed_ms(f, reps=5):
             f()
             barrier()
@@ -236,15 +242,17 @@ def main():
         breakdown = {"compute_only_ms": round(compute_ms, 4), "allgather_plus_unpack_only_ms": round(exchange_ms, 4),
                      "bytes_received_per_gpu": int((world - 1) * M * n_loc * 4),
                      "compute_only_gflops_total": round(flops_total / (compute_ms * 1e-3) / 1e9, 1)}
+      except Exception as e:   # the breakdown is a courtesy: it must never cost the contract line
+        breakdown = {"error": repr(e)[:200]}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, ptr, idx, vals, B_loc, M, n_loc)
 
     if rank == 0:
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if world == 1 and name == "C1" and os.path.exists(tp):
+        if not multi and name == "C1" and os.path.exists(tp):
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
@@ -279,7 +287,7 @@ def main():
         if breakdown is not None:
             line["multi_gpu_breakdown"] = breakdown
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,45 @@
+"""bench.py's contract line (driver contract + roofline / cpu_baseline objects), on a down-sized workload,
+and a rehearsal of its N>1 code path (RCCL group, panel pipeline, breakdown legs) with a world of one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--M", "65536", "--steps", "3", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = _run("--cpu-rows", "16384", "--check")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["unit"] == "GFLOP/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
+    assert abs(d["value"] - 2.0 * d["config"]["nnz"] * d["config"]["N"] / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+
+
+def test_multi_gpu_path_rehearsal():
+    d = _run("--rehearse-multi", "--no-cpu-baseline", "--check", "--panels", "3")
+    assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
+    b = d["multi_gpu_breakdown"]
+    assert "error" not in b and b["compute_only_ms"] > 0 and b["allgather_plus_unpack_only_ms"] > 0
+    assert d["roofline"] is None and d["cpu_baseline"] is None
