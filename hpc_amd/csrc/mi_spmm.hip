@@ -115,7 +115,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     lap(2);
     PlanOut po;
     const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);
-    const int rc = build_plan_gpu(h->d_ptr, M, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
+    const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
                                   (int32_t)h->long_chunk, &po);
     if (d_bad) (void)hipFree(d_bad);
     h->d_chunks = po.d_chunks;
@@ -645,6 +645,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     }
 
     const bool blocks_on = h->n_blk_groups > 0 && vec4;
+    const bool remap_blocks = h->xcd_remap != 0;   // list is column-ordered: keep neighbours on one XCD
     if (blocks_on && do_long) {
         BlockArgs ba;
         ba.groups = h->d_blk_groups;
@@ -657,6 +658,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ba.ldc = ldc;
         ba.n_groups = h->n_blk_groups;
         ba.N = N;
+        ba.remap = remap_blocks ? 1 : 0;
         const int slabs = N >= 256 ? N / 256 : 1;
         dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
         launch_blocks(N, wide, ba, bgrid, s);

@@ -534,6 +534,7 @@ struct BlockArgs {
     int64_t ldc;
     int32_t n_groups;
     int32_t N;
+    int32_t remap;           // 1: XCD remap of blockIdx.x (the group list is ordered by first column)
 };
 
 typedef float float4a __attribute__((ext_vector_type(4)));
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gi = (int)blockIdx.x * 4 + wave;
+    const int vblk = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int gi = vblk * 4 + wave;
     if (gi >= a.n_groups) return;
     float *lds = lds_all + wave * (KT * SLD);
     const int g = a.groups[gi];
