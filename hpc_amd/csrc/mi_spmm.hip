@@ -35,6 +35,7 @@ struct mi_spmm_handle {
     int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel
     int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
+    int64_t block_ablate;  // timing-only ablations of spmm_blocks (2: no B loads, 4: no MFMA); results are wrong
     int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
     // plan
@@ -240,6 +241,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
     else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
+    else if (k == "block_ablate") h->block_ablate = v;
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
@@ -659,9 +661,17 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ba.n_groups = h->n_blk_groups;
         ba.N = N;
         ba.remap = remap_blocks ? 1 : 0;
-        const int slabs = N >= 256 ? N / 256 : 1;
-        dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
-        launch_blocks(N, wide, ba, bgrid, s);
+        {
+            const int slabs = N >= 256 ? N / 256 : 1;
+            dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
+            if (h->block_ablate && N >= 256 && !wide) {   // timing-only builds of the 256-column kernel
+                if (h->block_ablate == 2) hipLaunchKernelGGL((spmm_blocks<16, false, 2>), bgrid, dim3(kBlockThreads), 0, s, ba);
+                else if (h->block_ablate == 4) hipLaunchKernelGGL((spmm_blocks<16, false, 4>), bgrid, dim3(kBlockThreads), 0, s, ba);
+                else if (h->block_ablate == 8) hipLaunchKernelGGL((spmm_blocks<16, false, 8>), bgrid, dim3(kBlockThreads), 0, s, ba);
+                else if (h->block_ablate == 14) hipLaunchKernelGGL((spmm_blocks<16, false, 14>), bgrid, dim3(kBlockThreads), 0, s, ba);
+                else hipLaunchKernelGGL((spmm_blocks<16, false, 6>), bgrid, dim3(kBlockThreads), 0, s, ba);
+            } else launch_blocks(N, wide, ba, bgrid, s);
+        }
         ++launches;
     }
 

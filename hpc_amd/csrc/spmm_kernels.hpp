@@ -557,7 +557,9 @@ __device__ __forceinline__ void wave_lds_sync()
 // -> ds_write_b128 into the wave's LDS slice (row pitch N_slab+16 floats: the 4 k-rows of an MFMA
 // operand land on disjoint banks) -> per 4-k step one A-fragment dword and TILES x (ds_read_b32 +
 // MFMA).  The next batch's global loads are issued before the current batch's MFMAs.
-template <int TILES, bool WIDE>
+// ABL: timing-only ablations (cdna_hip_programming.md section 7, step 2): 2 = no B loads, 4 = no MFMA, 8 = no C stores.
+// Compile-time on purpose: as a run-time branch inside the MFMA loop it wrecked the schedule (5x slower).
+template <int TILES, bool WIDE, int ABL = 0>
 __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_blocks(BlockArgs a)
 {
     constexpr int NS = 16 * TILES;        // slab width in floats
@@ -595,16 +597,19 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
     float4v R[LOADS];
     float af[KS];
 
+    // column indices run one batch ahead of the B rows they address (cj_next holds batch kb's indices
+    // when prefetch(kb) is called), so a prefetch is one memory round trip, not two dependent ones
+    int cj_next = (lane < KT && lane < L) ? a.col_idx[p0 + lane] : 0;
     auto prefetch = [&](int kb) {
-        // column indices of this batch: lane j holds cols[kb + j]
-        const int kk = kb + lane;
-        const int cj = (lane < KT && kk < L) ? a.col_idx[p0 + kk] : 0;
+        const int cj = cj_next;
+        const int kk = kb + KT + lane;
+        cj_next = (lane < KT && kk < L) ? a.col_idx[p0 + kk] : 0;
 #pragma unroll
         for (int u = 0; u < LOADS; ++u) {
             const int j = u * RPI + q_in;
             const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
             R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-            if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
+            if (kb + j < L && !(ABL & 2)) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -632,18 +637,37 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s], b, acc[t], 0, 0, 0);
+                if (!(ABL & 4)) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s], b, acc[t], 0, 0, 0);
+                else acc[t][0] += b * acur[s];  // ablation: keep the LDS read and the A value live
             }
         }
     }
-    // D reg q of lane l -> C[r0 + 4*kq + q][slab0 + 16t + i16]
+    // Epilogue.  D reg q of lane l is C[r0 + 4*kq + q][slab0 + 16t + i16]: stored directly that is 4-byte
+    // elements in 64-byte runs (64 store instructions per lane, 30 % write amplification, 16 % of the
+    // kernel).  Instead the tile goes through the wave's LDS slice, at most 128 columns at a time, and
+    // leaves as whole 16-byte-per-lane row segments.
+    constexpr int EH = (TILES > 8) ? 8 : TILES;      // tiles per epilogue pass
+    constexpr int ENS = 16 * EH;                     // columns per pass
+    constexpr int LDT = ENS + 4;                     // pitch: rows 4 apart land 16 banks apart
+    constexpr int ELPR = ENS / 4;                    // lanes per row when reading back
+    constexpr int ERPI = 64 / ELPR;                  // rows per store instruction
+    static_assert(16 * LDT <= KT * SLD, "epilogue tile must fit the staging slice");
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        const int col = slab0 + 16 * t + i16;
-        if (col < a.N) {
+    for (int h = 0; h < TILES / EH; ++h) {
+        wave_lds_sync();
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_nontemporal_store(acc[t][q], a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + col);
+        for (int t = 0; t < EH; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lds[(4 * kq + q) * LDT + 16 * t + i16] = acc[h * EH + t][q];
+        wave_lds_sync();
+        if (!(ABL & 8) || acc[0][0] == 12345.678f) {
+#pragma unroll
+            for (int it = 0; it < 16 / ERPI; ++it) {
+                const int row = it * ERPI + lane / ELPR;
+                const int c4 = 4 * (lane % ELPR);
+                const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
+                __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4));
+            }
         }
     }
 }
