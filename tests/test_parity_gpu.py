@@ -295,6 +295,7 @@ def test_block_path_bitwise(device, oracle, N):
     assert np.array_equal(bits(C0), bits(ref))
 
 
+
 @pytest.mark.parametrize("L", [8, 9, 11, 12, 31, 32, 33, 64, 65, 127, 256, 257, 500])
 def test_block_path_list_lengths(device, oracle, L):
     """Every tail shape of the k loop (batches of 8/16/32/64 k-rows, MFMA k-steps of 4)."""
@@ -307,11 +308,12 @@ def test_block_path_list_lengths(device, oracle, L):
 
 def test_block_path_on_block_dense_config(device, oracle):
     """BASELINE configs[4] family (down-sized): every row >= 64 contiguous nonzeros, N = 256."""
-    ptr, idx = synth.csr_block_dense_fast(8192)
+    M = 1 << 17          # enough groups (8192) that persistent waves walk several each
+    ptr, idx = synth.csr_block_dense_fast(M)
     vals = synth.normal_f32(idx.size, 6)
-    B = synth.normal_f32(8192 * 256, 7).reshape(8192, 256)
+    B = synth.normal_f32(M * 256, 7).reshape(M, 256)
     C, op = run_spmm(device, ptr, idx, vals, B)
-    assert op.get_option("n_block_groups") == 8192 // 16
+    assert op.get_option("n_block_groups") == M // 16
     assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B)))
 
 
