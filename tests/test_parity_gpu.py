@@ -308,7 +308,7 @@ def test_block_path_list_lengths(device, oracle, L):
 
 def test_block_path_on_block_dense_config(device, oracle):
     """BASELINE configs[4] family (down-sized): every row >= 64 contiguous nonzeros, N = 256."""
-    M = 1 << 17          # enough groups (8192) that persistent waves walk several each
+    M = 1 << 17
     ptr, idx = synth.csr_block_dense_fast(M)
     vals = synth.normal_f32(idx.size, 6)
     B = synth.normal_f32(M * 256, 7).reshape(M, 256)
