@@ -10,7 +10,8 @@ keeps its B slice resident as a contiguous K x n_loc array.  The exchange is pip
 panels: while panel p's column blocks travel, panel p+1's rows are being computed:
 
     compute stream :  rows(p0) | rows(p1) | rows(p2) | ...
-    comm stream    :           | gather(p0) unpack(p0) | gather(p1) unpack(p1) | ...
+    comm stream    :           | gather(p0) | gather(p1) | gather(p2) | ...      (back to back: link-bound)
+    unpack stream  :                        | unpack(p0) | unpack(p1) | ...
 
 all_gather_into_tensor delivers rank-major blocks staging[G][rows][n_loc] (an all-gather
 concatenates contiguous per-rank buffers -- SURVEY.md H4); `unpack` writes them into the
@@ -93,7 +94,7 @@ class ColumnShardedSpMM:
         if self.use_streams is None:
             self.use_streams = like.is_cuda
         if self.use_streams and self._streams is None:
-            self._streams = torch.cuda.Stream(device=like.device)
+            self._streams = (torch.cuda.Stream(device=like.device), torch.cuda.Stream(device=like.device))
 
     def run(self, B_loc, C_loc, C_full):
         import torch
@@ -105,24 +106,39 @@ class ColumnShardedSpMM:
             self.op.run_rows(B_loc, L.n_loc, C_full, L.N_total, 0, L.M)
             return
         self._ensure_buffers(C_loc)
-        comm = self._streams
-        main = torch.cuda.current_stream() if self.use_streams else None
-        if self.use_streams:
-            comm.wait_stream(main)  # staging/C_full reuse across calls
+        if not self.use_streams:
+            for p, (r0, r1) in enumerate(self.panels):
+                rows = r1 - r0
+                self.op.run_rows(B_loc, L.n_loc, C_loc, L.n_loc, r0, r1)
+                src = C_loc.view(-1)[r0 * L.n_loc: r1 * L.n_loc]
+                stage = self._staging[p & 1][: L.world * rows * L.n_loc]
+                dist.all_gather_into_tensor(stage, src, group=self.group)
+                self.unpack(stage, C_full.view(-1)[r0 * L.N_total:], rows, L.world, L.n_loc, L.N_total)
+            return
+        comm, post = self._streams
+        main = torch.cuda.current_stream()
+        comm.wait_stream(main)   # earlier work on the caller's stream (previous step's readers of C_full, staging)
+        post.wait_stream(main)
+        unpacked = [None, None]  # per staging buffer: event after the unpack that last read it
         for p, (r0, r1) in enumerate(self.panels):
             rows = r1 - r0
             self.op.run_rows(B_loc, L.n_loc, C_loc, L.n_loc, r0, r1)
+            computed = torch.cuda.Event()
+            computed.record(main)
             src = C_loc.view(-1)[r0 * L.n_loc: r1 * L.n_loc]
             stage = self._staging[p & 1][: L.world * rows * L.n_loc]
-            if self.use_streams:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ev)
-                    dist.all_gather_into_tensor(stage, src, group=self.group)
-                    self.unpack(stage, C_full.view(-1)[r0 * L.N_total:], rows, L.world, L.n_loc, L.N_total)
-            else:
+            with torch.cuda.stream(comm):
+                comm.wait_event(computed)
+                if unpacked[p & 1] is not None:
+                    comm.wait_event(unpacked[p & 1])     # the buffer's previous contents have been consumed
                 dist.all_gather_into_tensor(stage, src, group=self.group)
+                gathered = torch.cuda.Event()
+                gathered.record(comm)
+            with torch.cuda.stream(post):
+                post.wait_event(gathered)
                 self.unpack(stage, C_full.view(-1)[r0 * L.N_total:], rows, L.world, L.n_loc, L.N_total)
-        if self.use_streams:
-            main.wait_stream(comm)
+                done = torch.cuda.Event()
+                done.record(post)
+                unpacked[p & 1] = done
+        main.wait_stream(comm)
+        main.wait_stream(post)
