@@ -73,3 +73,30 @@ def test_product_never_touches_the_oracle():
                         s = line.strip()
                         if s.startswith(("#include", "import ", "from ")) or "CDLL" in s or "-l" in s:
                             assert "oracle" not in s, f"{dirpath}/{f}: {s}"
+
+
+def test_no_cpu_fallback_in_the_operator():
+    """The host mirror refuses host tensors instead of computing on the CPU, and the loader raises when the
+    HIP library is missing: a green run can only come from the gfx950 kernels."""
+    import numpy as np
+    import pytest
+    import torch
+
+    from hpc_amd import CSR, SpMMOpt, _lib
+
+    ptr = torch.zeros(3, dtype=torch.int32)
+    idx = torch.zeros(0, dtype=torch.int32)
+    val = torch.zeros(0, dtype=torch.float32)
+    with pytest.raises(TypeError, match="device tensor"):
+        CSR(2, 0, ptr, idx, val)
+    # loader: a missing library is an error, not a fallback
+    real = _lib.LIB_PATH
+    try:
+        _lib._lib = None
+        _lib.LIB_PATH = real + ".missing"
+        with pytest.raises(_lib.MiSpmmLibraryMissing):
+            _lib.load()
+    finally:
+        _lib.LIB_PATH = real
+        _lib._lib = None
+        _lib.load()
