@@ -598,3 +598,31 @@ def test_gpu_and_host_plan_builders_agree(device, oracle):
             assert np.array_equal(bits(res[1][0]), bits(res[0][0])), (name, thr)
             t = res[1][1]["long_row_threshold"]
             assert np.array_equal(bits(res[1][0]), bits(oracle.spmm_chunked(ptr, idx, vals, B, t, 64))), (name, thr)
+
+
+def test_unaligned_pointers_fall_back_cleanly(device, oracle):
+    """B/C that are only 4-byte aligned cannot use the 16-byte or the MFMA block path: the dword rows kernel
+    takes over every unsplit row (including the rows of detected block groups) with identical bits."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx, vals, B, kinds = _shared_list_case(30, 1200, 128, seed=321)
+    extra = np.sort(np.random.Generator(np.random.Philox(key=[5, 5])).choice(1200, 300, replace=False)).astype(np.int32)
+    idx = np.concatenate([idx, extra])
+    ptr = np.concatenate([ptr, [ptr[-1] + extra.size]]).astype(np.int32)       # one medium row as well
+    vals = synth.normal_f32(idx.size, 1)
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val = to_dev(device, ptr, idx, vals)
+    Bbuf = torch.zeros(1200 * 128 + 1, device=device)
+    Bbuf[1:] = torch.from_numpy(B.reshape(-1)).to(device)
+    Cbuf = torch.full((M * 128 + 1,), float("nan"), device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), 128, num_cols=1200)
+    op.set_option("long_row_threshold", 2048)
+    op.preprocess(Bbuf[1:], Cbuf[1:])
+    assert op.get_option("n_block_groups") > 0 and op.get_option("n_medium_rows") > 0
+    op.run(Bbuf[1:], Cbuf[1:])
+    torch.cuda.synchronize()
+    assert op.get_option("vector_width") == 1
+    got = Cbuf[1:].view(M, 128).cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+    assert torch.isnan(Cbuf[0])
