@@ -56,7 +56,9 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
     // wave-level reduction, one atomic per wave
     int m = len;
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&stats->max_len, m);
+    // one same-address atomic per wave was most of this kernel's time (16 K waves): skip it unless it can raise the max
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&stats->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&stats->max_len, m);
     if (bad) atomicOr(&stats->bad, bad);   // malformed input only
 }
 
@@ -104,10 +106,10 @@ __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__
 }
 
 namespace {
-struct DevBuf {   // frees on scope exit
+struct DevBuf {   // temporary from the stream-ordered pool (hipMalloc/hipFree cost ~0.1 ms each and synchronise)
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    ~DevBuf() { if (p) (void)hipFreeAsync(p, 0); }
+    hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 16, 0); }
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 }  // namespace
