@@ -80,7 +80,10 @@ static void free_plan(mi_spmm_handle *h)
     h->prepared = false;
 }
 
-static bool block_path_shape_ok(int32_t N) { return N == 32 || N == 64 || N == 128 || (N >= 256 && N % 256 == 0); }
+// The block kernel works on column slabs of 256/128/64/32 columns (blockIdx.y walks them): any N that is
+// a multiple of 32 qualifies, with the widest slab that divides it.
+static int block_slab_width(int32_t N) { return N <= 0 ? 0 : (N % 256 == 0 ? 256 : N % 128 == 0 ? 128 : N % 64 == 0 ? 64 : N % 32 == 0 ? 32 : 0); }
+static bool block_path_shape_ok(int32_t N) { return block_slab_width(N) != 0; }
 
 // preprocess with no host pass over the rows: column check, block detection, classification, scans,
 // segment emission and the length sort all run on the device; one small copy comes back.
@@ -552,17 +555,17 @@ void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s)
 }
 
 template <bool WIDE>
-void launch_blocks_w(int N, const BlockArgs &a, dim3 grid, hipStream_t s)
+void launch_blocks_w(int slab, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
-    if (N == 32) hipLaunchKernelGGL((spmm_blocks<2, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (N == 64) hipLaunchKernelGGL((spmm_blocks<4, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (N == 128) hipLaunchKernelGGL((spmm_blocks<8, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    if (slab == 32) hipLaunchKernelGGL((spmm_blocks<2, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (slab == 64) hipLaunchKernelGGL((spmm_blocks<4, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (slab == 128) hipLaunchKernelGGL((spmm_blocks<8, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
     else hipLaunchKernelGGL((spmm_blocks<16, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
 }
-void launch_blocks(int N, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
+void launch_blocks(int slab, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
-    if (wide) launch_blocks_w<true>(N, a, grid, s);
-    else launch_blocks_w<false>(N, a, grid, s);
+    if (wide) launch_blocks_w<true>(slab, a, grid, s);
+    else launch_blocks_w<false>(slab, a, grid, s);
 }
 
 int pow2_ceil(int x)
@@ -662,15 +665,15 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ba.N = N;
         ba.remap = remap_blocks ? 1 : 0;
         {
-            const int slabs = N >= 256 ? N / 256 : 1;
+            const int slab = block_slab_width(N), slabs = N / slab;
             dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
-            if (h->block_ablate && N >= 256 && !wide) {   // timing-only builds of the 256-column kernel
+            if (h->block_ablate && slab == 256 && !wide) {   // timing-only builds of the 256-column kernel
                 if (h->block_ablate == 2) hipLaunchKernelGGL((spmm_blocks<16, false, 2>), bgrid, dim3(kBlockThreads), 0, s, ba);
                 else if (h->block_ablate == 4) hipLaunchKernelGGL((spmm_blocks<16, false, 4>), bgrid, dim3(kBlockThreads), 0, s, ba);
                 else if (h->block_ablate == 8) hipLaunchKernelGGL((spmm_blocks<16, false, 8>), bgrid, dim3(kBlockThreads), 0, s, ba);
                 else if (h->block_ablate == 14) hipLaunchKernelGGL((spmm_blocks<16, false, 14>), bgrid, dim3(kBlockThreads), 0, s, ba);
                 else hipLaunchKernelGGL((spmm_blocks<16, false, 6>), bgrid, dim3(kBlockThreads), 0, s, ba);
-            } else launch_blocks(N, wide, ba, bgrid, s);
+            } else launch_blocks(slab, wide, ba, bgrid, s);
         }
         ++launches;
     }

@@ -281,7 +281,7 @@ def _shared_list_case(n_groups, K, N, seed, lens=None, tail_rows=5):
     return ptr, idx, vals, B, kinds
 
 
-@pytest.mark.parametrize("N", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("N", [32, 64, 96, 128, 160, 192, 256, 384, 512])
 def test_block_path_bitwise(device, oracle, N):
     ptr, idx, vals, B, kinds = _shared_list_case(60, 3000, N, seed=300 + N)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
