@@ -49,7 +49,7 @@ struct mi_spmm_handle {
     int32_t max_row_nnz;
     double preprocess_us;
     double phase_us[5];  // d2h row_ptr + validate, column check, block detection, host segment table, upload
-    int32_t last_lpr, last_v, last_launches;
+    int32_t last_lpr, last_v, last_launches, last_wide;
     // block (MFMA) path
     int64_t block_min_len;
     uint8_t *d_blk_flag;
@@ -278,6 +278,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_launches") *value = h->last_launches;
     else if (k == "lanes_per_row") *value = h->last_lpr;
     else if (k == "vector_width") *value = h->last_v;
+    else if (k == "wide_addressing") *value = h->last_wide;
     else if (k == "n_block_groups") *value = h->n_blk_groups;
     else if (k == "block_min_len") *value = h->block_min_len;
     else if (k == "preprocess_us") *value = (int64_t)h->preprocess_us;
@@ -722,6 +723,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         else hipLaunchKernelGGL((spmm_reduce_chunks<1>), rgrid, dim3(kBlockThreads), 0, s, ra);
         ++launches;
     }
+    h->last_wide = wide ? 1 : 0;
     h->last_lpr = lpr;
     h->last_v = V;
     h->last_launches = launches;

@@ -626,3 +626,39 @@ def test_unaligned_pointers_fall_back_cleanly(device, oracle):
     got = Cbuf[1:].view(M, 128).cpu().numpy()
     assert np.array_equal(bits(got), bits(oracle.spmm_omp(ptr, idx, vals, B)))
     assert torch.isnan(Cbuf[0])
+
+
+def test_wide_addressing_variants(device, oracle):
+    """The narrow kernels use a 32-bit byte offset per gathered B row (host-checked: K <= 2^24, pitch < 16 MiB,
+    B <= 4 GiB).  A row pitch of 4 Mi floats forces the 64-bit ("wide") variants of every kernel."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    K, N, ldb = 96, 128, (1 << 22) + 8
+    ptr, idx, vals, Bs, kinds = _shared_list_case(20, K, N, seed=808)              # block groups + ragged rows
+    g = np.random.Generator(np.random.Philox(key=[8, 8]))
+    extra = [g.integers(0, K, size=d).astype(np.int32) for d in (700, 150)]          # a split row and a medium row
+    idx = np.concatenate([idx] + extra)
+    ptr = np.concatenate([ptr, ptr[-1] + np.cumsum([e.size for e in extra])]).astype(np.int32)
+    vals = synth.normal_f32(idx.size, 2)
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val = to_dev(device, ptr, idx, vals)
+    d_B = torch.zeros(K * ldb, device=device)                                          # 1.6 GB, only N columns per row used
+    d_B.view(K, ldb)[:, :N] = torch.from_numpy(Bs).to(device)
+    d_C = torch.full((M, N), float("nan"), device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+    op.set_option("long_row_threshold", 256)
+    op.preprocess(d_B, d_C)
+    assert op.get_option("n_block_groups") > 0 and op.get_option("n_long_rows") == 1 and op.get_option("n_medium_rows") >= 1
+    op.run_ld(d_B, ldb, d_C, N)
+    torch.cuda.synchronize()
+    assert op.get_option("wide_addressing") == 1 and op.get_option("vector_width") == 4
+    exp = oracle.spmm_chunked(ptr, idx, vals, Bs, 256, 256)
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    for kernel in (1, 2):
+        op.set_option("kernel", kernel)
+        d_C.fill_(float("nan"))
+        op.run_ld(d_B, ldb, d_C, N)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)), kernel
+    del d_B
