@@ -68,9 +68,11 @@ def csr_uniform(M, deg_lo, deg_hi, K=None, seed=SEED_STRUCT):
     return _finish_rows(M, K, deg, g)
 
 
-def csr_powerlaw(M, mean_deg=32.0, max_deg=4096, alpha=1.5, K=None, seed=SEED_STRUCT):
+def csr_powerlaw(M, mean_deg=32.0, max_deg=4096, alpha=1.5, K=None, seed=SEED_STRUCT, force_max=False):
     """C2: degree_i = min(max_deg, floor(d_min * u^(-1/alpha))), d_min solved (bisection on
-    this very sample) so that the mean degree is mean_deg; rows are NOT sorted by degree."""
+    this very sample) so that the mean degree is mean_deg; rows are NOT sorted by degree.
+    force_max: give the longest row exactly max_deg nonzeros (dataset-shaped stand-ins whose
+    logged max degree a finite sample would not reach)."""
     K = M if K is None else K
     g = _rng(seed, 1)
     u = g.random(M)
@@ -84,6 +86,8 @@ def csr_powerlaw(M, mean_deg=32.0, max_deg=4096, alpha=1.5, K=None, seed=SEED_ST
         else:
             hi = mid
     deg = np.minimum(max_deg, np.floor(hi * w)).astype(np.int64)
+    if force_max and M > 0:
+        deg[int(np.argmax(deg))] = min(max_deg, K)
     return _finish_rows(M, K, deg, g)
 
 
