@@ -609,7 +609,10 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     const int bt = (v2 && vec4 && !wide) ? (int)h->block_threads : kBlockThreads;
     const int gpb = bt / lpr;
     int rpb = (int)h->rows_per_block;
-    if (rpb <= 0) rpb = v2 ? gpb : gpb * 8;  // v2: one row per lane group; v1: 8
+    // v2: one row per lane group -- except narrow groups on very short rows (N <= 32, mean degree < 12), where a second
+    // row per group lets the next row's pairs be fetched under the current row's few gathers (+3-6 %, profiles/r01_thresholds.txt)
+    const bool short_rows = lpr == 8 && M > 0 && h->nnz / M < 12;
+    if (rpb <= 0) rpb = v2 ? (short_rows ? 2 * gpb : gpb) : gpb * 8;
     if (rpb < gpb) rpb = gpb;
     int rpg = rpb / gpb;          // v2: contiguous rows per lane group, at most LPR - 1
     if (rpg > lpr - 1) rpg = lpr - 1;
