@@ -480,7 +480,15 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
     const LongRow L = a.rows[lr];
     const float *p = a.partials + (int64_t)L.first_slot * a.ldp + col;
     typename Vec<V>::T acc = Vec<V>::load(p);
-    for (int i = 1; i < L.n_chunks; ++i) acc = Vec<V>::add(acc, Vec<V>::load(p + (int64_t)i * a.ldp));
+    int i = 1;
+    for (; i + 8 <= L.n_chunks; i += 8) {   // 8 independent loads in flight, then the adds in piece order
+        typename Vec<V>::T t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = Vec<V>::load(p + (int64_t)(i + u) * a.ldp);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = Vec<V>::add(acc, t[u]);
+    }
+    for (; i < L.n_chunks; ++i) acc = Vec<V>::add(acc, Vec<V>::load(p + (int64_t)i * a.ldp));
     Vec<V>::template store<true>(a.C + (int64_t)L.row * a.ldc + col, acc);
 }
 
