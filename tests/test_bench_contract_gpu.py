@@ -42,4 +42,24 @@ def test_multi_gpu_path_rehearsal():
     assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
     b = d["multi_gpu_breakdown"]
     assert "error" not in b and b["compute_only_ms"] > 0 and b["allgather_plus_unpack_only_ms"] > 0
-    assert d["roofline"] is None and d["cpu_baseline"] is None
+    assert d["cpu_baseline"] is None
+    r = d["roofline"]        # N>1: the same per-GPU kernel, timed on the compute-only leg
+    assert r["bound"] == "hbm" and r["traffic"] is None and abs(r["kernel_ms"] - b["compute_only_ms"]) < 1e-3
+
+
+def test_driver_launch_line_two_ranks_sharing_the_gpu():
+    """The driver's N=2 command (python -m torch.distributed.run ... bench.py --gpus 2), both ranks on cuda:0
+    over gloo (MI_SPMM_SHARE_GPU=1: RCCL refuses two ranks on one device).  One JSON line, from rank 0."""
+    env = dict(os.environ, MI_SPMM_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--M", "65536", "--check"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["N"] == 256 and d["config"]["cols_per_gpu"] == 128
+    assert "rehearsal" in d and d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
+    assert "error" not in d["multi_gpu_breakdown"]
+    assert abs(d["value"] - 2.0 * d["config"]["nnz"] * 256 / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3

@@ -1,0 +1,91 @@
+"""The N>1 product path on ONE MI355X: two (and three) ranks share cuda:0.
+
+RCCL refuses two ranks on one device, so the process group is gloo carrying device tensors;
+everything else is what bench.py --gpus N runs: hpc_amd.SpMMOpt.run_rows for the row panels,
+the compute / exchange / unpack streams of hpc_amd/dist.py, the HIP unpack kernel.  Checked:
+every rank ends with the row-major C a single operator with N_total columns produces, bit for
+bit, on repeated steps (staging reuse across steps and panels)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, M, n_loc, n_panels, kind, q):
+    import torch
+    import torch.distributed as dist
+
+    from hpc_amd import CSR, SpMMOpt, synth
+    from hpc_amd.dist import ColumnShardedSpMM, ShardLayout
+    from hpc_amd.spmm import unpack_gathered
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if kind == "powerlaw":
+            ptr, idx = synth.csr_powerlaw(M, 12.0, 3000, seed=21, force_max=True)
+        else:
+            ptr, idx = synth.csr_uniform(M, 0, 40, seed=5)
+        vals = synth.normal_f32(idx.size, 6)
+        blocks = [synth.normal_f32(M * n_loc, synth.SEED_B, stream=r).reshape(M, n_loc) for r in range(world)]
+        d_ptr, d_idx, d_val = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals))
+        B_loc = torch.from_numpy(blocks[rank]).to(dev)
+        C_loc = torch.empty(M, n_loc, device=dev)
+        C_full = torch.full((M, n_loc * world), float("nan"), device=dev)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
+        op.preprocess(B_loc, C_loc)
+        sh = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), unpack_gathered, n_panels=n_panels)
+        for _ in range(3):
+            sh.run(B_loc, C_loc, C_full)
+        torch.cuda.synchronize()
+        # the 1-GPU answer: one operator over all N_total columns of the concatenated B
+        B_all = torch.from_numpy(np.ascontiguousarray(np.concatenate(blocks, axis=1))).to(dev)
+        C_one = torch.empty(M, n_loc * world, device=dev)
+        one = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc * world)
+        one.set_option("long_row_threshold", op.get_option("long_row_threshold"))
+        one.preprocess(B_all, C_one)
+        one.run(B_all, C_one)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(C_full.view(torch.int32), C_one.view(torch.int32)))
+        q.put((rank, same, bool(sh.use_streams), int(torch.isnan(C_full).sum().item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,M,n_loc,n_panels,kind", [(2, 40000, 128, 8, "uniform"), (2, 30011, 32, 5, "powerlaw"),
+                                                         (3, 20000, 64, 4, "uniform")])
+def test_ranks_sharing_one_gpu_reproduce_the_single_gpu_result(world, M, n_loc, n_panels, kind):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, n_loc, n_panels, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=240) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, same, streams, nans in sorted(got):
+        assert streams, "the GPU run must use the three-stream pipeline"
+        assert nans == 0, f"rank {rank}: {nans} elements of C never written"
+        assert same, f"rank {rank}: gathered C differs from the single-operator C"
