@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--N", type=int, default=None, help="override dense columns per GPU")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--panels", type=int, default=8)
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "direct"],
+                    help="N>1: how the C blocks travel (auto = time both before the warm-up, keep the faster)")
     ap.add_argument("--opt", action="append", default=[], help="key=value handle option (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the workload the CPU baseline runs (default: all for C1)")
@@ -163,7 +165,10 @@ def main():
     t_pre = time.time() - t_pre
 
     sharded = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), unpack_gathered, n_panels=args.panels,
-                                force_collective=args.rehearse_multi)
+                                force_collective=args.rehearse_multi,
+                                exchange="allgather" if args.exchange == "auto" else args.exchange)
+    if world > 1 and args.exchange == "auto":
+        sharded.tune(d_Cloc)          # collective; untimed, before the warm-up
 
     def barrier():
         if multi:
@@ -242,14 +247,16 @@ def main():
         stage = torch.empty(world * M * n_loc, dtype=torch.float32, device=dev)
 
         def exchange():
-            dist.all_gather_into_tensor(stage, d_Cloc.view(-1))
+            sharded._exchange(stage, d_Cloc.view(-1), M)
             unpack_gathered(stage, d_Cfull, M, world, n_loc, n_total)
 
         exchange_ms = timed_ms(exchange, reps=3)
         del stage
         breakdown = {"compute_only_ms": round(compute_ms, 4), "allgather_plus_unpack_only_ms": round(exchange_ms, 4),
                      "bytes_received_per_gpu": int((world - 1) * M * n_loc * 4),
-                     "compute_only_gflops_total": round(flops_total / (compute_ms * 1e-3) / 1e9, 1)}
+                     "compute_only_gflops_total": round(flops_total / (compute_ms * 1e-3) / 1e9, 1),
+                     "exchange": sharded.exchange,
+                     "exchange_tuning_ms_first_panel": sharded.tuning}
       except Exception as e:   # the breakdown is a courtesy: it must never cost the contract line
         breakdown = {"error": repr(e)[:200]}
 
@@ -281,7 +288,7 @@ def main():
                 "workload": f"{name}: CSR SpMM M=K={M}, nnz={nnz} (deg mean {nnz / max(1, M):.1f}, max {int(np.diff(ptr).max()) if M else 0}), "
                             f"N={n_total} fp32 ({n_loc} columns per GPU), int32 indices",
                 "M": M, "K": M, "nnz": nnz, "N": n_total, "cols_per_gpu": n_loc,
-                "parallelism": "single GPU" if world == 1 else f"column-sharded x{world}, RCCL all-gather of C blocks, {args.panels} row panels",
+                "parallelism": "single GPU" if world == 1 else f"column-sharded x{world}, RCCL all-gather of C blocks ({sharded.exchange} schedule), {args.panels} row panels",
                 "options": {k: op.get_option(k) for k in ("kernel", "rows_per_block", "block_threads", "xcd_remap", "nt_store", "nt_stream",
                                                           "long_row_threshold", "long_row_chunk", "n_long_rows", "n_chunks",
                                                           "lanes_per_row", "vector_width", "n_launches")},

@@ -17,6 +17,14 @@ all_gather_into_tensor delivers rank-major blocks staging[G][rows][n_loc] (an al
 concatenates contiguous per-rank buffers -- SURVEY.md H4); `unpack` writes them into the
 row-major C[rows][G*n_loc] the interface promises (a HIP kernel on the GPU path).
 
+Two exchange schedules fill the same staging layout:
+  "allgather"  the library collective (RCCL chooses rings/trees over the xGMI mesh);
+  "direct"     all-pairs: one grouped launch of G-1 sends of this rank's block and G-1 receives
+               straight into staging[peer] -- on the fully connected 8-GPU node every pair has
+               its own link, so all 7 links of a GPU carry one block each at the same time.
+`tune()` times both on the first panel's real sizes and keeps the faster (max over ranks, so all
+ranks agree); any failure of "direct" leaves "allgather".
+
 The class is device-agnostic host logic: the local operator and the unpack step are passed in.
 Product use (bench.py): op = hpc_amd.SpMMOpt, unpack = hpc_amd.spmm.unpack_gathered.  The
 world_size-2 gloo tests on CPU drive the same schedule with test doubles.
@@ -71,8 +79,15 @@ class ColumnShardedSpMM:
     """run(B_loc, C_loc, C_full): C_loc[M][n_loc] = A * B_loc (this rank's block, scratch the
     caller owns), C_full[M][G*n_loc] = all blocks, row-major, identical on every rank."""
 
+    EXCHANGES = ("allgather", "direct")
+
     def __init__(self, op, layout: ShardLayout, unpack: Callable, n_panels: int = 8,
-                 group=None, use_streams: Optional[bool] = None, force_collective: bool = False):
+                 group=None, use_streams: Optional[bool] = None, force_collective: bool = False,
+                 exchange: str = "allgather"):
+        if exchange not in self.EXCHANGES:
+            raise ValueError(f"exchange must be one of {self.EXCHANGES}")
+        self.exchange = exchange
+        self.tuning = None       # {"allgather": ms, "direct": ms | None} after tune()
         self.op = op
         self.layout = layout
         self.unpack = unpack
@@ -96,6 +111,78 @@ class ColumnShardedSpMM:
         if self.use_streams and self._streams is None:
             self._streams = (torch.cuda.Stream(device=like.device), torch.cuda.Stream(device=like.device))
 
+    def _peer(self, r):
+        import torch.distributed as dist
+
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def _exchange(self, stage, src, rows):
+        """Fill stage[G][rows][n_loc] with every rank's `src` block (on the current stream)."""
+        import torch.distributed as dist
+
+        L = self.layout
+        if self.exchange == "allgather" or L.world == 1:
+            dist.all_gather_into_tensor(stage, src, group=self.group)
+            return
+        blk = rows * L.n_loc
+        ops = []
+        for d in range(1, L.world):          # rank r sends to r+d while it receives from r-d: every step is a perfect matching
+            to, frm = (L.rank + d) % L.world, (L.rank - d) % L.world
+            ops.append(dist.P2POp(dist.isend, src, self._peer(to), group=self.group))
+            ops.append(dist.P2POp(dist.irecv, stage[frm * blk: (frm + 1) * blk], self._peer(frm), group=self.group))
+        stage[L.rank * blk: (L.rank + 1) * blk].copy_(src)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def tune(self, C_loc, reps: int = 3):
+        """Time both exchange schedules on the first panel's sizes and keep the faster one.
+        Collective: every rank must call it.  Leaves self.exchange set identically on all ranks."""
+        import time
+        import torch
+        import torch.distributed as dist
+
+        L = self.layout
+        if L.world == 1 or not self.panels:
+            return self.exchange
+        self._ensure_buffers(C_loc)
+        r0, r1 = self.panels[0]
+        rows = r1 - r0
+        src = C_loc.view(-1)[r0 * L.n_loc: r1 * L.n_loc]
+        stage = self._staging[0][: L.world * rows * L.n_loc]
+        cuda = C_loc.is_cuda
+        result = {}
+        where = C_loc.device if cuda else "cpu"
+
+        def agree(x, op):
+            v = torch.tensor([x], dtype=torch.float64, device=where)
+            dist.all_reduce(v, op=op, group=self.group)
+            return float(v.item())
+
+        for name in self.EXCHANGES:
+            self.exchange = name
+            ok = 1.0
+            try:
+                self._exchange(stage, src, rows)           # first use: communicator / connection set-up
+                if cuda:
+                    torch.cuda.synchronize()
+            except Exception:                              # e.g. a backend without p2p for this tensor type
+                if name == "allgather":
+                    raise
+                ok = 0.0
+            if agree(ok, dist.ReduceOp.MIN) < 1.0:         # some rank could not: nobody times it
+                result[name] = None
+                continue
+            dist.barrier(group=self.group)
+            t = time.perf_counter()
+            for _ in range(reps):
+                self._exchange(stage, src, rows)
+            if cuda:
+                torch.cuda.synchronize()
+            result[name] = agree((time.perf_counter() - t) * 1e3 / reps, dist.ReduceOp.MAX)   # the slowest rank's time
+        self.tuning = result
+        self.exchange = "direct" if result["direct"] is not None and result["direct"] < 0.97 * result["allgather"] else "allgather"
+        return self.exchange
+
     def run(self, B_loc, C_loc, C_full):
         import torch
         import torch.distributed as dist
@@ -112,7 +199,7 @@ class ColumnShardedSpMM:
                 self.op.run_rows(B_loc, L.n_loc, C_loc, L.n_loc, r0, r1)
                 src = C_loc.view(-1)[r0 * L.n_loc: r1 * L.n_loc]
                 stage = self._staging[p & 1][: L.world * rows * L.n_loc]
-                dist.all_gather_into_tensor(stage, src, group=self.group)
+                self._exchange(stage, src, rows)
                 self.unpack(stage, C_full.view(-1)[r0 * L.N_total:], rows, L.world, L.n_loc, L.N_total)
             return
         comm, post = self._streams
@@ -131,7 +218,7 @@ class ColumnShardedSpMM:
                 comm.wait_event(computed)
                 if unpacked[p & 1] is not None:
                     comm.wait_event(unpacked[p & 1])     # the buffer's previous contents have been consumed
-                dist.all_gather_into_tensor(stage, src, group=self.group)
+                self._exchange(stage, src, rows)
                 gathered = torch.cuda.Event()
                 gathered.record(comm)
             with torch.cuda.stream(post):

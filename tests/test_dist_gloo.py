@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of the column-sharded driver.
+"""The N>1 path on CPU: world_size-2 (3, 4) gloo runs of the column-sharded driver, both exchange schedules.
 
 The host logic under test is hpc_amd/dist.py (column blocks, row panels, all-gather, unpack).
 The device pieces are replaced by test doubles: the local operator is the oracle restricted to
@@ -58,7 +58,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, M, n_loc, n_panels, q):
+def _worker(rank, world, port, M, n_loc, n_panels, q, exchange="allgather"):
     import torch
     import torch.distributed as dist
 
@@ -72,9 +72,16 @@ def _worker(rank, world, port, M, n_loc, n_panels, q):
         vals = synth.normal_f32(idx.size, 6)
         B_loc = torch.from_numpy(synth.normal_f32(M * n_loc, synth.SEED_B, stream=rank).reshape(M, n_loc))
         op = OracleRowsOp(ptr, idx, vals)
-        sh = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), torch_unpack, n_panels=n_panels, use_streams=False)
-        C_loc = torch.empty(M, n_loc)
+        sh = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), torch_unpack, n_panels=n_panels, use_streams=False,
+                               exchange="allgather" if exchange == "tune" else exchange)
+        C_loc = torch.zeros(M, n_loc)
         C_full = torch.full((M, n_loc * world), float("nan"))
+        if exchange == "tune":
+            chosen = sh.tune(C_loc, reps=2)
+            assert chosen in sh.EXCHANGES and sh.tuning["allgather"] > 0 and sh.tuning["direct"] > 0
+            picks = [None] * world
+            dist.all_gather_object(picks, chosen)
+            assert len(set(picks)) == 1, picks          # every rank kept the same schedule
         sh.run(B_loc, C_loc, C_full)
         sh.run(B_loc, C_loc, C_full)      # idempotent, staging reuse
         q.put((rank, C_full.numpy().copy(), list(op.calls)))
@@ -82,15 +89,17 @@ def _worker(rank, world, port, M, n_loc, n_panels, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,M,n_loc,n_panels", [(2, 1000, 16, 3), (2, 777, 5, 1), (3, 600, 8, 4)])
-def test_gloo_column_sharded_matches_single_process(world, M, n_loc, n_panels):
+@pytest.mark.parametrize("world,M,n_loc,n_panels,exchange", [(2, 1000, 16, 3, "allgather"), (2, 777, 5, 1, "allgather"), (3, 600, 8, 4, "allgather"),
+                                                              (2, 1000, 16, 3, "direct"), (3, 600, 8, 4, "direct"), (4, 515, 4, 2, "direct"),
+                                                              (3, 600, 8, 4, "tune")])
+def test_gloo_column_sharded_matches_single_process(world, M, n_loc, n_panels, exchange):
     import torch.multiprocessing as mp
     from oracle import oracle
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, M, n_loc, n_panels, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, n_loc, n_panels, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, M, n_loc, n_panels, kind, q):
+def _worker(rank, world, port, M, n_loc, n_panels, kind, exchange, q):
     import torch
     import torch.distributed as dist
 
@@ -48,7 +48,7 @@ def _worker(rank, world, port, M, n_loc, n_panels, kind, q):
         C_full = torch.full((M, n_loc * world), float("nan"), device=dev)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
         op.preprocess(B_loc, C_loc)
-        sh = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), unpack_gathered, n_panels=n_panels)
+        sh = ColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), unpack_gathered, n_panels=n_panels, exchange=exchange)
         for _ in range(3):
             sh.run(B_loc, C_loc, C_full)
         torch.cuda.synchronize()
@@ -66,15 +66,15 @@ def _worker(rank, world, port, M, n_loc, n_panels, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,M,n_loc,n_panels,kind", [(2, 40000, 128, 8, "uniform"), (2, 30011, 32, 5, "powerlaw"),
-                                                         (3, 20000, 64, 4, "uniform")])
-def test_ranks_sharing_one_gpu_reproduce_the_single_gpu_result(world, M, n_loc, n_panels, kind):
+@pytest.mark.parametrize("world,M,n_loc,n_panels,kind,exchange", [(2, 40000, 128, 8, "uniform", "allgather"), (2, 30011, 32, 5, "powerlaw", "allgather"),
+                                                                  (3, 20000, 64, 4, "uniform", "allgather"), (3, 20000, 64, 4, "uniform", "direct")])
+def test_ranks_sharing_one_gpu_reproduce_the_single_gpu_result(world, M, n_loc, n_panels, kind, exchange):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, M, n_loc, n_panels, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, n_loc, n_panels, kind, exchange, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:
