@@ -2,10 +2,12 @@
 //
 // Host side of the drop-in: what SpMMOpt::preprocess / SpMMOpt::run do in the
 // reference (PA4/workspace/src/spmm_opt.cu:37-75), re-designed for MI355X:
-//   preprocess: D2H row_ptr, validate, pick out the long rows, build the chunk
-//               table, allocate the partial-sum workspace (handle-owned);
-//   run:        rows kernel (+ chunks + reduce when long rows exist) on the
-//               caller's stream; overwrite semantics; no host sync.
+//   preprocess: validate the CSR, detect block groups, classify rows and build the
+//               segment table on the device (preprocess_gpu.hip; the reference-style
+//               host loop stays behind gpu_preprocess=0), allocate the partial-sum
+//               workspace (handle-owned);
+//   run:        rows kernel (+ segments + reduce + blocks where such rows exist) on
+//               the caller's stream; overwrite semantics; no host sync.
 #include "../../include/mi_spmm.h"
 #include "plan.hpp"
 #include "spmm_kernels.hpp"
@@ -627,10 +629,8 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     const int pol = (h->nt_store ? kPolNtStore : 0) | (h->nt_stream ? kPolNtStream : 0);
     int launches = 0;
 
-    // long rows: all of them are produced by the call whose range starts at row 0
-    // (d_vout is the full-height local C in every call of a panel sequence)
-    const bool do_long = row_begin == 0;
-    if (h->n_chunks > 0 && do_long) {
+    // segment, block and reduce kernels walk their whole tables and keep the rows of this call's range
+    if (h->n_chunks > 0) {
         ChunkArgs ca;
         ca.chunks = h->d_chunks;
         ca.col_idx = h->d_idx;
@@ -644,6 +644,8 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ca.n_chunks = h->n_chunks;
         ca.N = N;
         ca.flags = flags;
+        ca.row_lo = row_begin;
+        ca.row_hi = row_end;
         const int cgpb = kBlockThreads / lpr;  // the chunk kernel always runs 256-thread workgroups
         dim3 cgrid((h->n_chunks + cgpb - 1) / cgpb, col_tiles);
         // partial rows are ldp (multiple of 4) floats and hipMalloc-aligned, so only
@@ -655,7 +657,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
 
     const bool blocks_on = h->n_blk_groups > 0 && vec4;
     const bool remap_blocks = h->xcd_remap != 0;   // list is column-ordered: keep neighbours on one XCD
-    if (blocks_on && do_long) {
+    if (blocks_on) {
         BlockArgs ba;
         ba.groups = h->d_blk_groups;
         ba.row_ptr = h->d_ptr;
@@ -668,6 +670,8 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ba.n_groups = h->n_blk_groups;
         ba.N = N;
         ba.remap = remap_blocks ? 1 : 0;
+        ba.row_lo = row_begin;
+        ba.row_hi = row_end;
         {
             const int slab = block_slab_width(N), slabs = N / slab;
             dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
@@ -710,7 +714,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     else launch_rows_any(vec4, wide, lpr, a, grid, s);
     if (rows_needed) ++launches;
 
-    if (h->n_long > 0 && do_long) {
+    if (h->n_long > 0) {
         ReduceArgs ra;
         ra.rows = h->d_long;
         ra.partials = h->d_partials;
@@ -720,6 +724,8 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ra.n_long = h->n_long;
         ra.N = N;
         ra.flags = flags;
+        ra.row_lo = row_begin;
+        ra.row_hi = row_end;
         const int64_t threads = (int64_t)h->n_long * ((N + V - 1) / V);
         dim3 rgrid((unsigned)((threads + kBlockThreads - 1) / kBlockThreads));
         if (vec4) hipLaunchKernelGGL((spmm_reduce_chunks<4>), rgrid, dim3(kBlockThreads), 0, s, ra);

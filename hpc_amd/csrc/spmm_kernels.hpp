@@ -429,6 +429,7 @@ struct ChunkArgs {
     int32_t n_chunks;
     int32_t N;
     int32_t flags;
+    int32_t row_lo, row_hi;  // only segments of rows in [row_lo, row_hi) are computed (row panels)
 };
 
 template <int V, int LPR, int UNROLL, bool WIDE>
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
     const bool col_ok = col_raw < a.N;
     const int col = col_ok ? col_raw : a.N - V;
     Chunk c = a.chunks[ch];
+    if (c.row < a.row_lo || c.row >= a.row_hi) return;   // uniform over the lane group
     int beg = c.beg, end = c.end;
     if (LPR == 64) {
         beg = __builtin_amdgcn_readfirstlane(beg);
@@ -467,6 +469,7 @@ struct ReduceArgs {
     int32_t n_long;
     int32_t N;
     int32_t flags;
+    int32_t row_lo, row_hi;
 };
 
 template <int V>
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
     if (lr >= a.n_long) return;
     const int col = (int)(t % vec_per_row) * V;
     const LongRow L = a.rows[lr];
+    if (L.row < a.row_lo || L.row >= a.row_hi) return;
     const float *p = a.partials + (int64_t)L.first_slot * a.ldp + col;
     typename Vec<V>::T acc = Vec<V>::load(p);
     int i = 1;
@@ -543,6 +547,7 @@ struct BlockArgs {
     int32_t n_groups;
     int32_t N;
     int32_t remap;           // 1: XCD remap of blockIdx.x (the group list is ordered by first column)
+    int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are not stored; groups wholly outside are skipped
 };
 
 typedef float float4a __attribute__((ext_vector_type(4)));
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
     float *lds = lds_all + wave * (KT * SLD);
     const int g = a.groups[gi];
     const int r0 = g << 4;
+    if (r0 + 16 <= a.row_lo || r0 >= a.row_hi) return;   // wave-uniform (the kernel has no workgroup barrier)
     const int i16 = lane & 15, kq = lane >> 4;
     const int slab0 = (int)blockIdx.y * NS;
 
@@ -674,7 +680,8 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
                 const int row = it * ERPI + lane / ELPR;
                 const int c4 = 4 * (lane % ELPR);
                 const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
-                __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4));
+                if (r0 + row >= a.row_lo && r0 + row < a.row_hi)
+                    __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4));
             }
         }
     }

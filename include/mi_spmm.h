@@ -91,8 +91,8 @@ int mi_spmm_run_ld(mi_spmm_handle *h, const float *d_vin, int64_t ldb,
 
 /* Same for the row range [row_begin, row_end) only (d_vout is still the base of
  * the full-height C): lets the multi-GPU driver compute C in row panels and
- * overlap each panel's all-gather with the next panel's kernel.  Rows longer
- * than the split threshold are all produced by the call with row_begin == 0. */
+ * overlap each panel's all-gather with the next panel's kernel.  Exactly the
+ * rows of the range are written, whatever kernel class they belong to. */
 int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb,
                      float *d_vout, int64_t ldc, int32_t row_begin,
                      int32_t row_end, void *stream);

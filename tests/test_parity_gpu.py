@@ -336,6 +336,54 @@ def test_block_path_with_row_panels_and_pitches(device, oracle):
     assert torch.isnan(wide[:, :128]).all()
 
 
+@pytest.mark.parametrize("N", [32, 128, 36])
+def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N):
+    """mi_spmm_run_rows on an arbitrary range: exactly those rows of C are written -- short rows, medium rows
+    (segment kernel), split rows (pieces + ordered reduce) and rows of block groups cut by the range boundary."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx, vals, B, kinds = _shared_list_case(30, 2500, N, seed=4242)
+    # append hub and medium rows so every class is present
+    g = np.random.Generator(np.random.Philox(key=[4243, 0]))
+    extra = [int(x) for x in (700, 90, 1500, 70, 3, 0, 300)]
+    cols = [np.sort(g.choice(2500, d, replace=False)).astype(np.int32) for d in extra]
+    ptr = np.concatenate([ptr, ptr[-1] + np.cumsum(extra)]).astype(np.int32)
+    idx = np.concatenate([idx] + cols).astype(np.int32)
+    vals = synth.normal_f32(idx.size, 11)
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=2500)
+    op.set_option("long_row_threshold", 256)
+    full = torch.empty(M, N, dtype=torch.float32, device=device)
+    op.preprocess(d_B, full)
+    assert op.get_option("n_long_rows") >= 3 and op.get_option("n_medium_rows") >= 2
+    if N % 32 == 0:
+        assert op.get_option("n_block_groups") > 0
+    op.run(d_B, full)
+    ref_full = full.cpu().numpy()
+    # split rows carry the documented tolerance against the oracle; everything else is bit-exact
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    unsplit = np.diff(ptr) <= 256
+    assert np.array_equal(bits(ref_full)[unsplit], bits(exp)[unsplit])
+    for r0, r1 in ((0, M), (5, 6), (7, 41), (100, 333), (M - 9, M), (M - 7, M - 2), (17, 17)):
+        C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+        op.run_rows(d_B, N, C, N, r0, r1)
+        torch.cuda.synchronize()
+        got = C.cpu().numpy()
+        assert np.array_equal(bits(got[r0:r1]), bits(ref_full[r0:r1])), (r0, r1)
+        outside = np.ones(M, bool)
+        outside[r0:r1] = False
+        assert np.isnan(got[outside]).all(), f"rows outside [{r0},{r1}) were written"
+    # a ragged cover of [0, M): same C as one call
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    cuts = [0, 3, 50, 51, 190, 402, M]
+    for r0, r1 in zip(cuts, cuts[1:]):
+        op.run_rows(d_B, N, C, N, r0, r1)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(C.cpu().numpy()), bits(ref_full))
+
+
 def test_gather_pipeline_on_gpu_streams(device, oracle):
     """The multi-GPU step's device side (compute stream / comm stream / staging / unpack kernel),
     rehearsed on one GPU with a world_size-1 RCCL group forced through the collective path."""
