@@ -115,7 +115,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     if (h->block_path && block_path_shape_ok(h->feat) && M >= 16 && h->nnz > 0) {
         const int32_t n_groups = (M + 15) / 16;
         if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) { if (d_bad) (void)hipFree(d_bad); return MI_SPMM_ENOMEM; }
-        hipLaunchKernelGGL(detect_row_blocks, dim3((n_groups + 3) / 4), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M,
+        hipLaunchKernelGGL(detect_row_blocks, dim3((n_groups + 3) / 4), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M, (int32_t)h->nnz,
                            (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
     }
     lap(2);
@@ -366,7 +366,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
             const int32_t n_groups = (M + 15) / 16;
             if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
             const int grid = (n_groups + 3) / 4;  // one wave per group
-            hipLaunchKernelGGL(detect_row_blocks, dim3(grid), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M,
+            hipLaunchKernelGGL(detect_row_blocks, dim3(grid), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M, (int32_t)h->nnz,
                                (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
             hipError_t e = hipGetLastError();
             std::vector<uint8_t> flags((size_t)n_groups);

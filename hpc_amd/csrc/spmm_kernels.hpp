@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
 // fetched ONCE per group instead of 16 times.
 __global__ __launch_bounds__(kBlockThreads) void detect_row_blocks(const int32_t *__restrict__ row_ptr,
                                                                   const int32_t *__restrict__ col_idx,
-                                                                  int32_t M, int32_t min_len, int32_t max_len,
+                                                                  int32_t M, int32_t nnz, int32_t min_len, int32_t max_len,
                                                                   uint8_t *__restrict__ flag)
 {
     const int lane = threadIdx.x & 63;
@@ -519,7 +519,8 @@ __global__ __launch_bounds__(kBlockThreads) void detect_row_blocks(const int32_t
 #pragma unroll
         for (int i = 0; i < 17; ++i) ps[i] = __builtin_amdgcn_readlane(p, i);  // wave-uniform row starts
         const int L = ps[1] - ps[0];
-        bool ok = L >= min_len && L <= max_len;
+        // runs before row_ptr has been validated: 16 equal positive lengths inside [0, nnz) keep every read below in bounds
+        bool ok = L >= min_len && L <= max_len && ps[0] >= 0 && ps[16] <= nnz && min_len > 0;
 #pragma unroll
         for (int i = 1; i < 16; ++i) ok = ok && (ps[i + 1] - ps[i] == L);
         if (ok) {                                              // uniform branch

@@ -214,6 +214,20 @@ def test_malformed_csr_is_rejected_not_faulted(device, gpu_pre):
         assert e.value.code == -4, why
         with pytest.raises(MiSpmmError):
             op.run(B, Cc)   # never prepared -> ESTATE, no launch
+    # shaped like a block group (16 rows of equal length >= 8, N a multiple of 32) but pointing far outside
+    # col_idx: block detection runs before row_ptr is validated on the device path and must not follow it
+    B32 = torch.zeros(M, 32, device=device)
+    C32 = torch.zeros(M, 32, device=device)
+    val128 = torch.ones(128, device=device)
+    idx128 = np.zeros(128, np.int32)
+    for why, ptr in {"offsets beyond nnz": (400_000_000 + 8 * np.arange(17)).astype(np.int32),
+                     "negative offsets": (-1_000_000 + 8 * np.arange(17)).astype(np.int32)}.items():
+        d_ptr, d_idx = to_dev(device, ptr, idx128)
+        op = SpMMOpt(CSR(M, 128, d_ptr, d_idx, val128), 32)
+        op.set_option("gpu_preprocess", gpu_pre)
+        with pytest.raises(MiSpmmError) as e:
+            op.preprocess(B32, C32)
+        assert e.value.code == -4, why
 
 
 def test_reference_kernel_agrees_with_oracle_live(device, oracle):
