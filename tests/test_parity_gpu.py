@@ -398,40 +398,6 @@ def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N
     assert np.array_equal(bits(C.cpu().numpy()), bits(ref_full))
 
 
-def test_run_is_capturable_in_a_hip_graph(device, oracle):
-    """run() neither synchronises nor allocates, so a step (here 4 launches: segments, blocks-free rows, reduce)
-    can be captured once and replayed -- the way a launch-bound caller would drive small graphs."""
-    import torch
-    from hpc_amd import CSR, SpMMOpt
-
-    M, N = 20000, 64
-    ptr, idx = synth.csr_powerlaw(M, 10.0, 3000, seed=77, force_max=True)
-    vals = synth.normal_f32(idx.size, 78)
-    B = synth.normal_f32(M * N, 79).reshape(M, N)
-    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
-    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
-    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N)
-    op.set_option("long_row_threshold", 256)
-    op.preprocess(d_B, C)
-    op.run(d_B, C)
-    torch.cuda.synchronize()
-    eager = C.clone()
-    assert op.get_option("n_launches") >= 3
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream(device=device)
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(g, stream=s):
-            op.run(d_B, C)           # launches go to torch's current (capturing) stream
-    for _ in range(3):
-        C.fill_(float("nan"))
-        g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(C.view(torch.int32), eager.view(torch.int32))
-    unsplit = np.diff(ptr) <= 256
-    assert np.array_equal(bits(C.cpu().numpy())[unsplit], bits(oracle.spmm_omp(ptr, idx, vals, B))[unsplit])
-
-
 def test_gather_pipeline_on_gpu_streams(device, oracle):
     """The multi-GPU step's device side (compute stream / comm stream / staging / unpack kernel),
     rehearsed on one GPU with a world_size-1 RCCL group forced through the collective path."""
