@@ -168,7 +168,11 @@ def main():
                                 force_collective=args.rehearse_multi,
                                 exchange="allgather" if args.exchange == "auto" else args.exchange)
     if world > 1 and args.exchange == "auto":
-        sharded.tune(d_Cloc)          # collective; untimed, before the warm-up
+        try:
+            sharded.tune(d_Cloc)      # collective; untimed, before the warm-up
+        except Exception as e:        # tuning is an optimisation: never lose the run over it
+            print(f"[bench] exchange tuning failed on rank {rank}: {e!r}; using the library all-gather", file=sys.stderr, flush=True)
+            sharded.exchange = "allgather"
 
     def barrier():
         if multi:
