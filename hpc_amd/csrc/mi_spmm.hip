@@ -40,6 +40,7 @@ struct mi_spmm_handle {
     int64_t block_ablate;  // timing-only ablations of spmm_blocks (2: no B loads, 4: no MFMA); results are wrong
     int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
+    int64_t segment_unroll;  // B-row gathers in flight per lane group in the segment kernel: 8, 16 or 32 (default)
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -211,6 +212,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->kernel = 2;
     h->gpu_preprocess = 1;
     h->block_threads = 256;
+    h->segment_unroll = 32; // whole 32-pair item in flight: 0-13 % faster than 8 on every shape (profiles/r01_segment_unroll.txt)
     *out = h;
     return MI_SPMM_OK;
 }
@@ -247,6 +249,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
     else if (k == "block_ablate") h->block_ablate = v;
+    else if (k == "segment_unroll") { if (v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
@@ -270,6 +273,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "kernel") *value = h->kernel;
     else if (k == "gpu_preprocess") *value = h->gpu_preprocess;
     else if (k == "block_threads") *value = h->block_threads;
+    else if (k == "segment_unroll") *value = h->segment_unroll;
     else if (k == "nt_store") *value = h->nt_store;
     else if (k == "nt_stream") *value = h->nt_stream;
     else if (k == "block_path") *value = h->block_path;
@@ -542,18 +546,22 @@ void launch_rows_v2_any(bool vec4, bool wide, int lpr, int bt, int pol, const Ro
 }
 
 template <int V, int LPR, bool WIDE>
-void launch_chunks(const ChunkArgs &a, dim3 grid, hipStream_t s)
+void launch_chunks(const ChunkArgs &a, dim3 grid, hipStream_t s, int deep)
 {
-    hipLaunchKernelGGL((spmm_chunks<V, LPR, 8, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    // deep = gathers in flight per lane group (16-byte narrow path; the fallbacks keep 8).  A segment is one
+    // long dependent chain per lane group, so more loads in flight is what buys speed; 32 = a whole item.
+    if (deep == 32 && V == 4 && !WIDE) hipLaunchKernelGGL((spmm_chunks<V, LPR, 32, false>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (deep == 16 && V == 4 && !WIDE) hipLaunchKernelGGL((spmm_chunks<V, LPR, 16, false>), grid, dim3(kBlockThreads), 0, s, a);
+    else hipLaunchKernelGGL((spmm_chunks<V, LPR, 8, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
 }
 template <int V, bool WIDE>
-void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s)
+void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s, int deep = 0)
 {
     switch (lpr) {
-    case 8: launch_chunks<V, 8, WIDE>(a, grid, s); break;
-    case 16: launch_chunks<V, 16, WIDE>(a, grid, s); break;
-    case 32: launch_chunks<V, 32, WIDE>(a, grid, s); break;
-    default: launch_chunks<V, 64, WIDE>(a, grid, s); break;
+    case 8: launch_chunks<V, 8, WIDE>(a, grid, s, deep); break;
+    case 16: launch_chunks<V, 16, WIDE>(a, grid, s, deep); break;
+    case 32: launch_chunks<V, 32, WIDE>(a, grid, s, deep); break;
+    default: launch_chunks<V, 64, WIDE>(a, grid, s, deep); break;
     }
 }
 
@@ -650,7 +658,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         dim3 cgrid((h->n_chunks + cgpb - 1) / cgpb, col_tiles);
         // partial rows are ldp (multiple of 4) floats and hipMalloc-aligned, so only
         // the B side decides the vector width here
-        if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, s); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, s); }
+        if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, s); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, s, (int)h->segment_unroll); }
         else { if (wide) launch_chunks_lpr<1, true>(lpr, ca, cgrid, s); else launch_chunks_lpr<1, false>(lpr, ca, cgrid, s); }
         ++launches;
     }
