@@ -34,7 +34,8 @@ struct mi_spmm_handle {
     int64_t nnz;
     // options
     int64_t long_thr_user;  // what the caller asked for (0 = auto); long_thr holds the resolved value
-    int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel
+    int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel; 0 = auto
+    int64_t medium_res;  // the value in force after preprocess (auto resolved, capped by long_thr)
     int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
     int64_t block_ablate;  // timing-only ablations of spmm_blocks (2: no B loads, 4: no MFMA); results are wrong
@@ -121,7 +122,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     }
     lap(2);
     PlanOut po;
-    const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);
+    const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);   // 0 = auto
     const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
                                   (int32_t)h->long_chunk, &po);
     if (d_bad) (void)hipFree(d_bad);
@@ -135,6 +136,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     h->n_medium = po.n_medium;
     h->n_blk_groups = po.n_blk_groups;
     h->max_row_nnz = po.max_len;
+    h->medium_res = po.mthr;
     if (h->n_blk_groups == 0 && h->d_blk_flag) { (void)hipFree(h->d_blk_flag); h->d_blk_flag = nullptr; }
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)h->n_medium;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
@@ -199,7 +201,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->num_cols = num_cols;
     h->nnz = nnz;
     h->feat = feat_in;
-    h->medium_thr = 64;
+    h->medium_thr = 0;     // auto: 64, or 32 on skewed degree distributions (resolved in preprocess)
     h->long_thr = 0;       // 0 = auto, resolved in preprocess: clamp(nnz / 8192, 256, 2048)
     h->long_thr_user = 0;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
@@ -241,7 +243,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
 {
     if (!good(h) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
-    if (k == "medium_row_threshold") { if (v < 1) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+    if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
     else if (k == "long_row_chunk") { if (v < 1) return MI_SPMM_EINVAL; h->long_chunk = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
@@ -264,7 +266,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     if (!good(h) || !key || !value) return MI_SPMM_EINVAL;
     const std::string k(key);
     if (k == "long_row_threshold") *value = h->long_thr;
-    else if (k == "medium_row_threshold") *value = h->medium_thr;
+    else if (k == "medium_row_threshold") *value = h->prepared ? h->medium_res : h->medium_thr;
     else if (k == "n_medium_rows") *value = h->n_medium;
     else if (k == "n_partial_slots") *value = h->n_slots;
     else if (k == "long_row_chunk") *value = h->long_chunk;
@@ -404,7 +406,11 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     std::vector<Chunk> chunks;
     std::vector<LongRow> longs;
     const int32_t thr = (int32_t)h->long_thr, clen = (int32_t)h->long_chunk;
-    const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);
+    // same auto rule as preprocess_gpu.hip resolve_mthr(): 32 on skewed degree distributions, else 64
+    const int64_t mean_len = M > 0 ? h->nnz / M : 0;
+    const int64_t mrule = h->medium_thr > 0 ? h->medium_thr : ((int64_t)max_len > 8 * (mean_len > 1 ? mean_len : 1) ? 32 : 64);
+    const int32_t mthr = (int32_t)(mrule < h->long_thr ? mrule : h->long_thr);
+    h->medium_res = mthr;
     int32_t n_slots = 0, n_medium = 0;
     if (max_len > mthr) {
         chunks.reserve(1 << 16);
@@ -711,7 +717,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     // when the block path cannot run here (unaligned pointers): then the rows kernel takes every
     // unsplit row again (medium rows are computed twice with identical bits; stream order keeps it benign)
     const bool blocks_fallback = h->n_blk_groups > 0 && !blocks_on;
-    a.long_thr = (int32_t)(blocks_fallback ? h->long_thr : (h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr));
+    a.long_thr = (int32_t)(blocks_fallback ? h->long_thr : h->medium_res);
     a.nblk = (int)nblk64;
     a.flags = flags;
     dim3 grid((unsigned)nblk64, col_tiles);

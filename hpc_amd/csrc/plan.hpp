@@ -15,11 +15,13 @@ struct PlanOut {
     int32_t *d_blk_groups = nullptr;  // [n_blk_groups] (only when d_blk_flag was given)
     int32_t n_chunks = 0, n_long = 0, n_slots = 0, n_medium = 0, n_blk_groups = 0;
     int32_t max_len = 0;
+    int32_t mthr = 0;               // resolved medium threshold (the rows kernel skips rows above it)
 };
 
 // Returns 0, a negative MI_SPMM_E* code (malformed CSR, out of memory) or a positive hipError_t.
 // d_blk_flag: per 16-row group, 1 = block path owns it (nullable).  col_bad: device flag written
 // by csr_check_cols earlier on the same (null) stream; read back with the same single copy.
+// mthr: medium threshold, 0 = auto (resolved on the device from the longest row, returned in PlanOut::mthr).
 // d_col_idx is only read to order the block groups by their first column (cache locality of the
 // shared B rows; scheduling only, never arithmetic).
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,

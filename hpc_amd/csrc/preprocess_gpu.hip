@@ -18,18 +18,41 @@ struct PlanStats {
     uint32_t bad;      // bit0: negative row length, bit1: ptr[0] < 0
     int32_t ptr0, ptrM;
     int32_t n_groups_selected;
-    int32_t pad[3];
+    int32_t mthr;      // resolved medium threshold (auto rule below, or the caller's value), already capped by thr
+    int32_t pad[2];
 };
 
+// Longest row, ahead of the classification: the auto medium threshold depends on it.
+__global__ __launch_bounds__(kBlockThreads) void row_len_max(const int32_t *__restrict__ row_ptr, int32_t M, PlanStats *stats)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    int m = (r < M) ? row_ptr[r + 1] - row_ptr[r] : 0;
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+    // one same-address atomic per wave was most of this kernel's time (16 K waves): skip it unless it can raise the max
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&stats->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&stats->max_len, m);
+}
+
+// Rows above the medium threshold leave the rows kernel for the length-sorted segment kernel.  auto: 64 when
+// the degrees are even (the rows kernel's lane groups finish together anyway), 32 when the longest row is more
+// than 8x the mean -- skewed graphs, where neighbours in a wave differ widely (profiles/r01_medium_threshold.txt).
+__device__ __forceinline__ int resolve_mthr(int mthr_user, int mean_len, int max_len, int thr)
+{
+    int m = mthr_user > 0 ? mthr_user : ((int64_t)max_len > 8 * (int64_t)(mean_len > 1 ? mean_len : 1) ? 32 : 64);
+    return m < thr ? m : thr;
+}
+
 __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__restrict__ row_ptr, int32_t M,
-                                                              const uint8_t *__restrict__ blk_flag, int32_t mthr,
-                                                              int32_t thr, int32_t clen, int32_t *__restrict__ seg_cnt,
+                                                              const uint8_t *__restrict__ blk_flag, int32_t mthr_user,
+                                                              int32_t mean_len, int32_t thr, int32_t clen,
+                                                              int32_t *__restrict__ seg_cnt,
                                                               int32_t *__restrict__ slot_cnt,
                                                               int32_t *__restrict__ long_cnt, PlanStats *stats)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
     int len = 0;
     unsigned bad = 0;
+    const int mthr = resolve_mthr(mthr_user, mean_len, stats->max_len, thr);   // max_len: complete (previous kernel)
     if (r < M) {
         const int beg = row_ptr[r], end = row_ptr[r + 1];
         len = end - beg;
@@ -46,19 +69,13 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
         seg_cnt[r] = segs;
         slot_cnt[r] = slots;
         long_cnt[r] = lng;
-        if (r == 0) { stats->ptr0 = beg; if (beg < 0) bad |= 2; }
+        if (r == 0) { stats->ptr0 = beg; stats->mthr = mthr; if (beg < 0) bad |= 2; }
         if (r == M - 1) stats->ptrM = end;
     } else if (r == M) {   // trailing zero so the exclusive scans leave the totals at index M
         seg_cnt[r] = 0;
         slot_cnt[r] = 0;
         long_cnt[r] = 0;
     }
-    // wave-level reduction, one atomic per wave
-    int m = len;
-    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
-    // one same-address atomic per wave was most of this kernel's time (16 K waves): skip it unless it can raise the max
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&stats->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(&stats->max_len, m);
     if (bad) atomicOr(&stats->bad, bad);   // malformed input only
 }
 
@@ -129,6 +146,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                    const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out)
 {
     *out = PlanOut();
+    out->mthr = (mthr > 0 ? mthr : 64) < thr ? (mthr > 0 ? mthr : 64) : thr;   // replaced by the device's value below
     if (M <= 0) return (nnz == 0) ? MI_SPMM_OK : MI_SPMM_ECSR;
     const size_t n1 = (size_t)M + 1;
     DevBuf cnt, off, stats, tmp, groups, ngroups;
@@ -139,8 +157,9 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     int32_t *seg_cnt = cnt.as<int32_t>(), *slot_cnt = seg_cnt + n1, *long_cnt = slot_cnt + n1;
     int32_t *seg_off = off.as<int32_t>(), *slot_off = seg_off + n1, *long_off = slot_off + n1;
     const unsigned grid = (unsigned)((n1 + kBlockThreads - 1) / kBlockThreads);
-    hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr, thr, clen,
-                       seg_cnt, slot_cnt, long_cnt, stats.as<PlanStats>());
+    hipLaunchKernelGGL(row_len_max, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats.as<PlanStats>());
+    hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
+                       (int32_t)(nnz / M), thr, clen, seg_cnt, slot_cnt, long_cnt, stats.as<PlanStats>());
     PLAN_TRY(hipGetLastError());
     size_t tb = 0, tb2 = 0;
     PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, seg_cnt, seg_off, (int)n1));
@@ -175,6 +194,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     // data.cu:40-45 asserts ptr[num_v] == num_e; monotone rows and in-range columns keep the kernels in bounds
     if (host.st.bad || host.col_bad || (int64_t)host.st.ptrM != nnz || host.st.ptr0 < 0) return MI_SPMM_ECSR;
     out->max_len = host.st.max_len;
+    out->mthr = host.st.mthr;
     out->n_chunks = host.n_chunks;
     out->n_slots = host.n_slots;
     out->n_long = host.n_long;

@@ -71,11 +71,12 @@ int mi_spmm_create(mi_spmm_handle **out,
 /* Replaces SpMM::set_feat (spmm_base.h:26-29).  Invalidates preprocess. */
 int mi_spmm_set_feat(mi_spmm_handle *h, int32_t feat_in);
 
-/* Replaces SpMMOpt::preprocess(vin, vout) (src/spmm_opt.cu:37-69): reads
- * row_ptr (device -> host), validates it, classifies rows, builds the launch
- * plan and the long-row chunk table, allocates the handle-owned workspace.
- * May synchronise the device (the reference's does: cudaMemcpy D2H, :39).
- * Unlike the reference it does NOT need vout zeroed and does not touch it. */
+/* Replaces SpMMOpt::preprocess(vin, vout) (src/spmm_opt.cu:37-69): validates
+ * the CSR, classifies the rows and builds the segment / split-row / block-group
+ * tables -- on the device, one small copy comes back -- and allocates the
+ * handle-owned workspace.  Synchronises the device (the reference's does:
+ * cudaMemcpy D2H, :39).  Unlike the reference it does NOT need vout zeroed and
+ * does not touch it. */
 int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout);
 
 /* Replaces SpMMOpt::run(vin, vout) (src/spmm_opt.cu:71-75).  stream is a
@@ -104,7 +105,9 @@ int mi_spmm_destroy(mi_spmm_handle *h);
 const char *mi_spmm_strerror(int code);
 
 /* Tuning / introspection.  Keys (all int64):
- *   "medium_row_threshold" rows longer than this run as ONE exact segment in the segment kernel
+ *   "medium_row_threshold" rows longer than this run as ONE exact segment in the segment kernel (0 = auto:
+ *                         64, or 32 when the longest row exceeds 8x the mean degree; get returns the
+ *                         resolved value after preprocess).  Scheduling only: results do not depend on it
  *   "long_row_threshold"  rows with more nonzeros are split into chunks (0 = auto:
  *                         clamp(nnz/8192, 256, 2048); get returns the resolved value after preprocess)
  *   "long_row_chunk"      chunk length in nonzeros
