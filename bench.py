@@ -294,7 +294,7 @@ def main():
                 "M": M, "K": M, "nnz": nnz, "N": n_total, "cols_per_gpu": n_loc,
                 "parallelism": "single GPU" if world == 1 else f"column-sharded x{world}, RCCL all-gather of C blocks ({sharded.exchange} schedule), {args.panels} row panels",
                 "options": {k: op.get_option(k) for k in ("kernel", "rows_per_block", "block_threads", "xcd_remap", "nt_store", "nt_stream",
-                                                          "long_row_threshold", "long_row_chunk", "n_long_rows", "n_chunks",
+                                                          "medium_row_threshold", "long_row_threshold", "long_row_chunk", "segment_unroll", "n_long_rows", "n_chunks",
                                                           "lanes_per_row", "vector_width", "n_launches")},
                 "preprocess_ms": round(t_pre * 1e3, 2), "preprocess_first_call_ms": round(t_pre_first * 1e3, 2), "input_gen_s": round(t_gen, 1),
             },
