@@ -137,7 +137,15 @@ def main():
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  Its kernels run beside a compute kernel that fills every CU: give them the
+            # high-priority queue so the exchange -- the link-bound part of the step -- is never the one waiting.
+            pg_opts = None
+            try:
+                pg_opts = dist.ProcessGroupNCCL.Options()
+                pg_opts.is_high_priority_stream = True
+            except Exception:
+                pg_opts = None
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=pg_opts)
 
     from hpc_amd import CSR, SpMMOpt, synth
     from hpc_amd.dist import ColumnShardedSpMM, ShardLayout

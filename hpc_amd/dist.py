@@ -109,7 +109,8 @@ class ColumnShardedSpMM:
         if self.use_streams is None:
             self.use_streams = like.is_cuda
         if self.use_streams and self._streams is None:
-            self._streams = (torch.cuda.Stream(device=like.device), torch.cuda.Stream(device=like.device))
+            # exchange and unpack at high priority: they must not queue behind a compute kernel that fills every CU
+            self._streams = (torch.cuda.Stream(device=like.device, priority=-1), torch.cuda.Stream(device=like.device, priority=-1))
 
     def _peer(self, r):
         import torch.distributed as dist
