@@ -576,29 +576,36 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
     import torch
     from hpc_amd import CSR, SpMMOpt
 
-    g = np.random.Generator(np.random.Philox(key=[2024, 1]))
-    for case in range(80):
+    n_cases = int(os.environ.get("MI_SPMM_FUZZ_CASES", "80"))          # soak: MI_SPMM_FUZZ_CASES=3000 MI_SPMM_FUZZ_SEED=7
+    fuzz_seed = int(os.environ.get("MI_SPMM_FUZZ_SEED", "1"))
+    g = np.random.Generator(np.random.Philox(key=[2024, fuzz_seed]))
+    for case in range(n_cases):
         M = int(g.integers(1, 400))
         K = int(g.integers(1, 500))
         N = int(g.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 33, 64, 96, 128, 130, 256, 300]))
         hi = int(g.choice([0, 3, 20, 90, min(K, 400)]))
-        ptr, idx = synth.csr_uniform(M, 0, min(hi, K), K=K, seed=1000 + case)
+        ptr, idx = synth.csr_uniform(M, 0, min(hi, K), K=K, seed=1000 * fuzz_seed + case)
         if idx.size and g.random() < 0.5:       # unsorted / duplicated columns inside rows
             idx = g.integers(0, K, size=idx.size).astype(np.int32)
         vals = synth.normal_f32(idx.size, 5000 + case)
         ldb = N + int(g.choice([0, 0, 4, 5, 64]))
         ldc = N + int(g.choice([0, 0, 4, 3, 128]))
         Bp = synth.normal_f32(K * ldb, 9000 + case).reshape(K, ldb)
-        opts = {"kernel": int(g.choice([1, 2])), "medium_row_threshold": int(g.choice([1, 5, 64, 1000])),
+        opts = {"kernel": int(g.choice([1, 2])), "medium_row_threshold": int(g.choice([0, 1, 5, 64, 1000])),
                 "long_row_threshold": int(g.choice([6, 40, 2048])), "long_row_chunk": int(g.choice([3, 16, 256])),
-                "block_path": int(g.choice([0, 1]))}
+                "block_path": int(g.choice([0, 1])), "segment_unroll": int(g.choice([8, 16, 32]))}
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
         d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
         for k, v in opts.items():
             op.set_option(k, v)
         op.preprocess(d_B, d_C)
-        op.run_ld(d_B, ldb, d_C, ldc)
+        if g.random() < 0.3 and M > 2:          # the same C from a ragged sequence of row-range calls
+            cuts = sorted(set([0, M] + [int(x) for x in g.integers(0, M, 3)]))
+            for r0, r1 in zip(cuts, cuts[1:]):
+                op.run_rows(d_B, ldb, d_C, ldc, r0, r1)
+        else:
+            op.run_ld(d_B, ldb, d_C, ldc)
         torch.cuda.synchronize()
         got = d_C.cpu().numpy()
         exp = oracle.spmm_chunked(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["long_row_threshold"], opts["long_row_chunk"])
