@@ -721,8 +721,8 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     a.nblk = (int)nblk64;
     a.flags = flags;
     dim3 grid((unsigned)nblk64, col_tiles);
-    // every row may already be owned by the block path (and the split path): nothing left to launch
-    const bool rows_needed = !(blocks_on && h->n_rows_for_rows_kernel == 0);
+    // every row may already be owned by the segment, split and block paths: nothing left to launch
+    const bool rows_needed = !((blocks_on || h->n_blk_groups == 0) && h->n_rows_for_rows_kernel == 0);
     if (!rows_needed) { /* skip */ }
     else if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
     else launch_rows_any(vec4, wide, lpr, a, grid, s);
