@@ -607,10 +607,12 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     if (!d_vin && h->nnz > 0) return MI_SPMM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
 
-    // 16-byte path needs 16-B aligned bases and pitches; anything else takes the
-    // dword path (same arithmetic, 4 B per lane).
-    const bool vec4 = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
-                      (((uintptr_t)d_vin | (uintptr_t)d_vout) & 15u) == 0;
+    // 16 bytes per lane whenever a row holds at least one float4: global dwordx4 accesses only need dword
+    // alignment, and a row whose width is not a multiple of 4 gets its last lane shifted back to column N - 4
+    // (spmm_kernels.hpp).  Only N < 4 takes the dword path.  The MFMA block path keeps the strict 16-byte rule.
+    const bool aligned16 = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
+                           (((uintptr_t)d_vin | (uintptr_t)d_vout) & 15u) == 0;
+    const bool vec4 = N >= 4;
     const int V = vec4 ? 4 : 1;
     // narrow addressing: byte offset of any B element < 2^32, column index and
     // row pitch in bytes < 2^24 (one v_mad_u32_u24 per gathered row)
@@ -669,7 +671,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ++launches;
     }
 
-    const bool blocks_on = h->n_blk_groups > 0 && vec4;
+    const bool blocks_on = h->n_blk_groups > 0 && aligned16;
     const bool remap_blocks = h->xcd_remap != 0;   // list is column-ordered: keep neighbours on one XCD
     if (blocks_on) {
         BlockArgs ba;
@@ -714,7 +716,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     a.N = N;
     a.rows_per_block = v2 ? rpg : rpb;
     // rows above the medium threshold were given to the segment kernel -- except rows of block groups
-    // when the block path cannot run here (unaligned pointers): then the rows kernel takes every
+    // when the block path cannot run here (pointers or pitches not 16-byte aligned): then the rows kernel takes every
     // unsplit row again (medium rows are computed twice with identical bits; stream order keeps it benign)
     const bool blocks_fallback = h->n_blk_groups > 0 && !blocks_on;
     a.long_thr = (int32_t)(blocks_fallback ? h->long_thr : h->medium_res);

@@ -69,12 +69,15 @@ enum : int { kPolNtStore = 1, kPolNtStream = 2 };
 template <int V> struct Vec;
 template <> struct Vec<4> {
     typedef float4v T;
+    // Memory accesses are declared 4-byte aligned: global_load/store_dwordx4 only needs dword alignment, so the
+    // same 16-byte-per-lane kernels serve odd widths and pitches (N = 127, 602, ...; rows then start at any dword).
+    typedef float4v U __attribute__((aligned(4)));
     static __device__ __forceinline__ T zero() { return (T){0.f, 0.f, 0.f, 0.f}; }
-    static __device__ __forceinline__ T load(const float *p) { return *reinterpret_cast<const T *>(p); }
+    static __device__ __forceinline__ T load(const float *p) { return *reinterpret_cast<const U *>(p); }
     template <bool NT> static __device__ __forceinline__ void store(float *p, T v)
     {
-        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
-        else *reinterpret_cast<T *>(p) = v;
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<U *>(p));
+        else *reinterpret_cast<U *>(p) = v;
     }
     // one v_fma_f32 per component: exactly fmaf(b, a, acc)
     static __device__ __forceinline__ T fma(T b, float a, T acc)
@@ -203,7 +206,9 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_rows(RowsArgs a)
     const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(blockIdx.x, a.nblk) : (int)blockIdx.x;
     const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
     const bool col_ok = col_raw < a.N;
-    const int col = col_ok ? col_raw : a.N - V;  // lanes past N load a valid column and store nothing
+    // lanes past N load a valid column and store nothing; when N is not a multiple of V the row's last lane is
+    // shifted back to N - V: it recomputes up to V-1 columns of its neighbour and both store the same bits
+    const int col = min(col_raw, a.N - V);
 
     const int r0 = a.row0 + vb * a.rows_per_block;
     const int r1 = min(a.M, r0 + a.rows_per_block);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
     const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(blockIdx.x, a.nblk) : (int)blockIdx.x;
     const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
     const bool col_ok = col_raw < a.N;
-    const int col = col_ok ? col_raw : a.N - V;
+    const int col = min(col_raw, a.N - V);   // see spmm_rows: tail lane shifted back, lanes past N store nothing
     const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)col * 4u;
 
     const int rpg = a.rows_per_block;  // here: rows per lane GROUP (<= LPR - 1)
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
     if (ch >= a.n_chunks) return;
     const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
     const bool col_ok = col_raw < a.N;
-    const int col = col_ok ? col_raw : a.N - V;
+    const int col = min(col_raw, a.N - V);   // see spmm_rows: tail lane shifted back, lanes past N store nothing
     Chunk c = a.chunks[ch];
     if (c.row < a.row_lo || c.row >= a.row_hi) return;   // uniform over the lane group
     int beg = c.beg, end = c.end;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
     const int64_t t = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
     const int64_t lr = t / vec_per_row;
     if (lr >= a.n_long) return;
-    const int col = (int)(t % vec_per_row) * V;
+    const int col = min((int)(t % vec_per_row) * V, a.N - V);   // tail vector shifted back like the producers'
     const LongRow L = a.rows[lr];
     if (L.row < a.row_lo || L.row >= a.row_hi) return;
     const float *p = a.partials + (int64_t)L.first_slot * a.ldp + col;

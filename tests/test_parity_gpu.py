@@ -38,7 +38,7 @@ def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
         C, op = run_spmm(device, ptr, idx, vals, B, options={"kernel": kernel})
         assert not np.isnan(C).any(), "output not fully overwritten"
         assert np.array_equal(bits(C), bits(ref)), f"kernel {kernel}: {(bits(C) != bits(ref)).sum()} elements differ"
-        assert op.get_option("vector_width") == (4 if N % 4 == 0 else 1)
+        assert op.get_option("vector_width") == (4 if N >= 4 else 1)   # 16 B per lane at any width >= 4 (dword-aligned dwordx4)
 
 
 @pytest.mark.parametrize("block_threads", [64, 128, 256])
@@ -670,8 +670,8 @@ def test_gpu_and_host_plan_builders_agree(device, oracle):
 
 
 def test_unaligned_pointers_fall_back_cleanly(device, oracle):
-    """B/C that are only 4-byte aligned cannot use the 16-byte or the MFMA block path: the dword rows kernel
-    takes over every unsplit row (including the rows of detected block groups) with identical bits."""
+    """B/C that are only 4-byte aligned cannot use the MFMA block path (it keeps the strict 16-byte rule): the rows
+    kernel -- still 16 bytes per lane, dword-aligned -- takes over the rows of detected block groups, identical bits."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
@@ -691,7 +691,7 @@ def test_unaligned_pointers_fall_back_cleanly(device, oracle):
     assert op.get_option("n_block_groups") > 0 and op.get_option("n_medium_rows") > 0
     op.run(Bbuf[1:], Cbuf[1:])
     torch.cuda.synchronize()
-    assert op.get_option("vector_width") == 1
+    assert op.get_option("vector_width") == 4
     got = Cbuf[1:].view(M, 128).cpu().numpy()
     assert np.array_equal(bits(got), bits(oracle.spmm_omp(ptr, idx, vals, B)))
     assert torch.isnan(Cbuf[0])
