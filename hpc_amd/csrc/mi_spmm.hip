@@ -41,6 +41,7 @@ struct mi_spmm_handle {
     int64_t block_ablate;  // timing-only ablations of spmm_blocks (2: no B loads, 4: no MFMA); results are wrong
     int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
+    int64_t split_cols;  // 1 (default): columns past the last full 256-column tile get their own launches
     int64_t segment_unroll;  // B-row gathers in flight per lane group in the segment kernel: 8, 16 or 32 (default)
     // plan
     bool prepared;
@@ -214,6 +215,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->kernel = 2;
     h->gpu_preprocess = 1;
     h->block_threads = 256;
+    h->split_cols = 1;
     h->segment_unroll = 32; // whole 32-pair item in flight: 0-13 % faster than 8 on every shape (profiles/r01_segment_unroll.txt)
     *out = h;
     return MI_SPMM_OK;
@@ -251,6 +253,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
     else if (k == "block_ablate") h->block_ablate = v;
+    else if (k == "split_cols") h->split_cols = v ? 1 : 0;
     else if (k == "segment_unroll") { if (v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -276,6 +279,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "gpu_preprocess") *value = h->gpu_preprocess;
     else if (k == "block_threads") *value = h->block_threads;
     else if (k == "segment_unroll") *value = h->segment_unroll;
+    else if (k == "split_cols") *value = h->split_cols;
     else if (k == "nt_store") *value = h->nt_store;
     else if (k == "nt_stream") *value = h->nt_stream;
     else if (k == "block_path") *value = h->block_path;
@@ -596,22 +600,19 @@ int pow2_ceil(int x)
 
 extern "C" {
 
-int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc,
-                     int32_t row_begin, int32_t row_end, void *stream)
-{
-    if (!good(h) || !h->prepared) return MI_SPMM_ESTATE;
-    const int32_t M = h->num_v, N = h->feat;
-    if (row_begin < 0 || row_end > M || row_begin > row_end) return MI_SPMM_EINVAL;
-    if (row_begin == row_end || N == 0) return MI_SPMM_OK;
-    if (!d_vout || ldc < N || ldb < N) return MI_SPMM_EINVAL;
-    if (!d_vin && h->nnz > 0) return MI_SPMM_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+// One column part [col0, col0 + N) of the step: d_vin / d_vout / partials already point at column col0.
+// The MFMA block kernel works on the whole width and is launched with the first part only (full = the
+// caller's original pointers and width).
+struct FullView { const float *B; float *C; int32_t N; };
 
+static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc, int32_t row_begin,
+                    int32_t row_end, hipStream_t s, int32_t N, int64_t col0, bool blocks_on, bool launch_blocks_here,
+                    const FullView &full, int *launches_out, bool record)
+{
+    const int32_t M = h->num_v;
     // 16 bytes per lane whenever a row holds at least one float4: global dwordx4 accesses only need dword
     // alignment, and a row whose width is not a multiple of 4 gets its last lane shifted back to column N - 4
     // (spmm_kernels.hpp).  Only N < 4 takes the dword path.  The MFMA block path keeps the strict 16-byte rule.
-    const bool aligned16 = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
-                           (((uintptr_t)d_vin | (uintptr_t)d_vout) & 15u) == 0;
     const bool vec4 = N >= 4;
     const int V = vec4 ? 4 : 1;
     // narrow addressing: byte offset of any B element < 2^32, column index and
@@ -652,7 +653,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ca.col_idx = h->d_idx;
         ca.vals = h->d_val;
         ca.B = d_vin;
-        ca.partials = h->d_partials;
+        ca.partials = h->d_partials + col0;
         ca.C = d_vout;
         ca.ldb = ldb;
         ca.ldp = h->ldp;
@@ -671,25 +672,24 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         ++launches;
     }
 
-    const bool blocks_on = h->n_blk_groups > 0 && aligned16;
     const bool remap_blocks = h->xcd_remap != 0;   // list is column-ordered: keep neighbours on one XCD
-    if (blocks_on) {
+    if (blocks_on && launch_blocks_here) {
         BlockArgs ba;
         ba.groups = h->d_blk_groups;
         ba.row_ptr = h->d_ptr;
         ba.col_idx = h->d_idx;
         ba.vals = h->d_val;
-        ba.B = d_vin;
-        ba.C = d_vout;
+        ba.B = full.B;
+        ba.C = full.C;
         ba.ldb = ldb;
         ba.ldc = ldc;
         ba.n_groups = h->n_blk_groups;
-        ba.N = N;
+        ba.N = full.N;
         ba.remap = remap_blocks ? 1 : 0;
         ba.row_lo = row_begin;
         ba.row_hi = row_end;
         {
-            const int slab = block_slab_width(N), slabs = N / slab;
+            const int slab = block_slab_width(full.N), slabs = full.N / slab;
             dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
             if (h->block_ablate && slab == 256 && !wide) {   // timing-only builds of the 256-column kernel
                 if (h->block_ablate == 2) hipLaunchKernelGGL((spmm_blocks<16, false, 2>), bgrid, dim3(kBlockThreads), 0, s, ba);
@@ -733,7 +733,7 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     if (h->n_long > 0) {
         ReduceArgs ra;
         ra.rows = h->d_long;
-        ra.partials = h->d_partials;
+        ra.partials = h->d_partials + col0;
         ra.C = d_vout;
         ra.ldp = h->ldp;
         ra.ldc = ldc;
@@ -748,12 +748,48 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
         else hipLaunchKernelGGL((spmm_reduce_chunks<1>), rgrid, dim3(kBlockThreads), 0, s, ra);
         ++launches;
     }
-    h->last_wide = wide ? 1 : 0;
-    h->last_lpr = lpr;
-    h->last_v = V;
-    h->last_launches = launches;
+    if (record) {
+        h->last_wide = wide ? 1 : 0;
+        h->last_lpr = lpr;
+        h->last_v = V;
+    }
+    *launches_out += launches;
     return (int)hipGetLastError();
 }
+
+}  // extern "C"  (run_part is internal)
+
+extern "C" {
+
+int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc,
+                     int32_t row_begin, int32_t row_end, void *stream)
+{
+    if (!good(h) || !h->prepared) return MI_SPMM_ESTATE;
+    const int32_t M = h->num_v, N = h->feat;
+    if (row_begin < 0 || row_end > M || row_begin > row_end) return MI_SPMM_EINVAL;
+    if (row_begin == row_end || N == 0) return MI_SPMM_OK;
+    if (!d_vout || ldc < N || ldb < N) return MI_SPMM_EINVAL;
+    if (!d_vin && h->nnz > 0) return MI_SPMM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool aligned16 = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
+                           (((uintptr_t)d_vin | (uintptr_t)d_vout) & 15u) == 0;
+    const bool blocks_on = h->n_blk_groups > 0 && aligned16;
+    const FullView full = {d_vin, d_vout, N};
+    // Widths just above a multiple of 256: the last 256-column tile would hold only a few columns yet run one
+    // row per wave.  Up to 64 such columns go to a second set of launches with their own, narrower lane groups:
+    // N = 257 / 260: -7 % time; wider remainders measured neutral, so they stay tiles of the one launch
+    // (profiles/r01_odd_widths.txt -- the partial tile is bound by the extra cache lines, not by instruction issue).
+    int32_t rem = (h->split_cols && N > 256) ? N % 256 : 0;
+    if (rem > 64) rem = 0;
+    int launches = 0;
+    int rc = run_part(h, d_vin, ldb, d_vout, ldc, row_begin, row_end, s, N - rem, 0, blocks_on, true, full, &launches, true);
+    if (rc == 0 && rem > 0)
+        rc = run_part(h, d_vin + (N - rem), ldb, d_vout + (N - rem), ldc, row_begin, row_end, s, rem, N - rem, blocks_on,
+                      false, full, &launches, false);
+    h->last_launches = launches;
+    return rc;
+}
+
 
 int mi_spmm_run_ld(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc,
                    void *stream)

@@ -114,6 +114,7 @@ const char *mi_spmm_strerror(int code);
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
  *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel (8, 16, 32; default 32)
+ *   "split_cols"          1 (default): up to 64 columns past the last full 256-column tile get their own launches
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto
  *   "gpu_preprocess"      1 (default): segment table built on the device; 0: reference-style host loop
  *   "kernel"              1: per-row fetch (spmm_rows), 2: pipelined items (spmm_rows_v2, default)

@@ -15,9 +15,13 @@ M = 1 << 20
 ptr, idx = synth.csr_uniform(M, 16, 48)
 vals = synth.make_values(idx.size)
 d = [torch.from_numpy(a).to(dev) for a in (ptr, idx, vals)]
-for N in (30, 32, 33, 63, 64, 100, 127, 128, 129, 130, 132, 200, 250, 256, 260):
+for N in (256, 257, 260, 300, 384, 500, 512, 602, 1000, 1024, 1433):
     B = torch.randn(M, N, device=dev) * 0.1; C = torch.empty(M, N, device=dev)
-    op = SpMMOpt(CSR(M, idx.size, *d), N); op.preprocess(B, C)
-    ms = timed(lambda: op.run(B, C))
     alg = 8 * idx.size + 4 * (M + 1) + 4 * N * idx.size + 4 * M * N
-    print(f"N={N:4d} V={op.get_option('vector_width')} lpr={op.get_option('lanes_per_row'):2d} {ms:7.3f} ms  {alg/ms/1e9:6.2f} TB/s", flush=True)
+    out = []
+    for sc in (0, 1):
+        op = SpMMOpt(CSR(M, idx.size, *d), N); op.set_option("split_cols", sc); op.preprocess(B, C)
+        ms = timed(lambda: op.run(B, C))
+        out.append(f"split_cols={sc}: {ms:7.3f} ms {alg/ms/1e9:5.2f} TB/s launches={op.get_option('n_launches')}")
+    print(f"N={N:4d}  " + "   ".join(out), flush=True)
+    del B, C

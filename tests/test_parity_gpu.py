@@ -29,7 +29,7 @@ def test_goldens_bitwise(device, path):
     assert np.array_equal(bits(C), bits(z["C_ref_kernel"]))
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 64, 100, 128, 132, 256, 260, 512, 1024])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 64, 100, 128, 132, 256, 257, 260, 300, 512, 602, 1024, 1433])
 def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
     M, K = 777, 513
     ptr, idx, vals, B = _rand_case(M, K, N, 0, 70, seed=100 + N)
@@ -582,7 +582,7 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
     for case in range(n_cases):
         M = int(g.integers(1, 400))
         K = int(g.integers(1, 500))
-        N = int(g.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 33, 64, 96, 128, 130, 256, 300]))
+        N = int(g.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 33, 64, 96, 128, 130, 256, 257, 300, 514, 602]))
         hi = int(g.choice([0, 3, 20, 90, min(K, 400)]))
         ptr, idx = synth.csr_uniform(M, 0, min(hi, K), K=K, seed=1000 * fuzz_seed + case)
         if idx.size and g.random() < 0.5:       # unsorted / duplicated columns inside rows
