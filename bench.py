@@ -46,8 +46,10 @@ def parse():
     ap.add_argument("--N", type=int, default=None, help="override dense columns per GPU")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--panels", type=int, default=8)
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "direct"],
-                    help="N>1: how the C blocks travel (auto = time both before the warm-up, keep the faster)")
+    ap.add_argument("--exchange", default="allgather", choices=["auto", "allgather", "direct"],
+                    help="N>1: how the C blocks travel.  allgather = RCCL's collective (default: the only schedule that could be "
+                         "rehearsed over RCCL from a one-GPU box); direct = all-pairs grouped send/recv; auto = time both before "
+                         "the warm-up and keep the faster")
     ap.add_argument("--opt", action="append", default=[], help="key=value handle option (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the workload the CPU baseline runs (default: all for C1)")
