@@ -38,11 +38,11 @@ struct mi_spmm_handle {
     int64_t medium_res;  // the value in force after preprocess (auto resolved, capped by long_thr)
     int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
-    int64_t block_ablate;  // timing-only ablations of spmm_blocks (2: no B loads, 4: no MFMA); results are wrong
     int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
     int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
     int64_t split_cols;  // 1 (default): columns past the last full 256-column tile get their own launches
     int64_t segment_unroll;  // B-row gathers in flight per lane group in the segment kernel: 8, 16 or 32 (default)
+    int64_t tile_cols;       // widest column tile of the rows/segment kernels: 256 (whole wave on a row), 128, 64, 32; 0 = auto
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -64,6 +64,9 @@ struct mi_spmm_handle {
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
+// Pieces of a split row: the plan builders step through a row in int32; a piece length far beyond any row
+// that can be split usefully would overflow `b + clen`.
+static const int64_t kMaxLongChunk = 1 << 20;
 
 static bool good(const mi_spmm_handle *h) { return h && h->magic == kMagic; }
 
@@ -120,6 +123,8 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) { if (d_bad) (void)hipFree(d_bad); return MI_SPMM_ENOMEM; }
         hipLaunchKernelGGL(detect_row_blocks, dim3((n_groups + 3) / 4), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M, (int32_t)h->nnz,
                            (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { if (d_bad) (void)hipFree(d_bad); free_plan(h); return (int)e; }
     }
     lap(2);
     PlanOut po;
@@ -247,13 +252,21 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     const std::string k(key);
     if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
-    else if (k == "long_row_chunk") { if (v < 1) return MI_SPMM_EINVAL; h->long_chunk = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+    else if (k == "long_row_chunk") { if (v < 1 || v > kMaxLongChunk) return MI_SPMM_EINVAL; h->long_chunk = v; free_plan(h); }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
-    else if (k == "kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->kernel = v; }
+    else if (k == "kernel") {
+#ifdef MI_SPMM_ABLATE
+        if (v != 1 && v != 2) return MI_SPMM_EINVAL;
+#else
+        if (v == 1) return MI_SPMM_EUNSUPPORTED;   // the first-generation rows kernel lives only in the A/B library (make ablate)
+        if (v != 2) return MI_SPMM_EINVAL;
+#endif
+        h->kernel = v;
+    }
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
-    else if (k == "block_ablate") h->block_ablate = v;
     else if (k == "split_cols") h->split_cols = v ? 1 : 0;
+    else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; }
     else if (k == "segment_unroll") { if (v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -280,6 +293,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "block_threads") *value = h->block_threads;
     else if (k == "segment_unroll") *value = h->segment_unroll;
     else if (k == "split_cols") *value = h->split_cols;
+    else if (k == "tile_cols") *value = h->tile_cols;
     else if (k == "nt_store") *value = h->nt_store;
     else if (k == "nt_stream") *value = h->nt_stream;
     else if (k == "block_path") *value = h->block_path;
@@ -437,7 +451,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
             L.first_slot = n_slots;
             L.n_chunks = 0;
             L.pad = 0;
-            for (int32_t b = beg; b < end; b += clen) {
+            for (int32_t b = beg; b < end; b += (end - b > clen ? clen : end - b)) {
                 Chunk c;
                 c.beg = b;
                 c.end = (end - b > clen) ? b + clen : end;
@@ -494,6 +508,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
 // ---- launch dispatch ------------------------------------------------------------
 namespace {
 
+#ifdef MI_SPMM_ABLATE
 // v1 rows kernel (per-row fetch, no prefetch): kept as the A/B baseline only, one configuration per shape.
 template <int V, bool WIDE>
 void launch_rows_v1(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
@@ -510,6 +525,8 @@ void launch_rows_any(bool vec4, bool wide, int lpr, const RowsArgs &a, dim3 grid
     if (vec4) { if (wide) launch_rows_v1<4, true>(lpr, a, grid, s); else launch_rows_v1<4, false>(lpr, a, grid, s); }
     else { if (wide) launch_rows_v1<1, true>(lpr, a, grid, s); else launch_rows_v1<1, false>(lpr, a, grid, s); }
 }
+
+#endif  // MI_SPMM_ABLATE
 
 // v2 rows kernel: the cache policy (nt C stores x nt (col,val) loads) and the workgroup size are
 // instantiated for the 16-byte narrow path, which every benchmark shape uses; the dword and
@@ -589,6 +606,14 @@ void launch_blocks(int slab, bool wide, const BlockArgs &a, dim3 grid, hipStream
     else launch_blocks_w<false>(slab, a, grid, s);
 }
 
+// auto: see profiles/r02_wide_n_tiles.txt
+int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
+{
+    if (h->tile_cols > 0) return (int)h->tile_cols;
+    (void)N; (void)ldb;
+    return 256;
+}
+
 int pow2_ceil(int x)
 {
     int p = 1;
@@ -622,6 +647,10 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     int lpr = pow2_ceil((N + V - 1) / V);
     if (lpr < 8) lpr = 8;
     if (lpr > 64) lpr = 64;
+    // Wide B (N >= 256): the column tiles are swept one after the other (blockIdx.x runs fastest), so a tile's
+    // working set is K rows x tile_cols x 4 B.  Narrower tiles keep that set nearer the Infinity Cache's size.
+    const int tile_cap = resolve_tile_cols(h, N, ldb) / V;
+    if (vec4 && lpr > tile_cap) lpr = tile_cap;
     const int tile_w = lpr * V;
     const int col_tiles = (N + tile_w - 1) / tile_w;
     const bool v2 = h->kernel == 2;
@@ -673,6 +702,9 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     }
 
     const bool remap_blocks = h->xcd_remap != 0;   // list is column-ordered: keep neighbours on one XCD
+    // the block kernel addresses the FULL width (this part may be narrower when split_cols peels a remainder)
+    const bool wide_full = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
+                             ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
     if (blocks_on && launch_blocks_here) {
         BlockArgs ba;
         ba.groups = h->d_blk_groups;
@@ -691,13 +723,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         {
             const int slab = block_slab_width(full.N), slabs = full.N / slab;
             dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
-            if (h->block_ablate && slab == 256 && !wide) {   // timing-only builds of the 256-column kernel
-                if (h->block_ablate == 2) hipLaunchKernelGGL((spmm_blocks<16, false, 2>), bgrid, dim3(kBlockThreads), 0, s, ba);
-                else if (h->block_ablate == 4) hipLaunchKernelGGL((spmm_blocks<16, false, 4>), bgrid, dim3(kBlockThreads), 0, s, ba);
-                else if (h->block_ablate == 8) hipLaunchKernelGGL((spmm_blocks<16, false, 8>), bgrid, dim3(kBlockThreads), 0, s, ba);
-                else if (h->block_ablate == 14) hipLaunchKernelGGL((spmm_blocks<16, false, 14>), bgrid, dim3(kBlockThreads), 0, s, ba);
-                else hipLaunchKernelGGL((spmm_blocks<16, false, 6>), bgrid, dim3(kBlockThreads), 0, s, ba);
-            } else launch_blocks(slab, wide, ba, bgrid, s);
+            launch_blocks(slab, wide_full, ba, bgrid, s);
         }
         ++launches;
     }
@@ -727,7 +753,9 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     const bool rows_needed = !((blocks_on || h->n_blk_groups == 0) && h->n_rows_for_rows_kernel == 0);
     if (!rows_needed) { /* skip */ }
     else if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
+#ifdef MI_SPMM_ABLATE
     else launch_rows_any(vec4, wide, lpr, a, grid, s);
+#endif
     if (rows_needed) ++launches;
 
     if (h->n_long > 0) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
             if (len <= thr) {
                 if (!(blk_flag && blk_flag[r >> 4])) segs = 1;   // medium row: one exact segment
             } else {
-                segs = slots = (len + clen - 1) / clen;          // hub: pieces + partial-sum slots
+                segs = slots = 1 + (len - 1) / clen;            // hub: pieces + partial-sum slots (len > thr >= 1; no int32 overflow)
                 lng = 1;
             }
         }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__
     L.n_chunks = n;
     L.pad = 0;
     longs[long_off[r]] = L;
-    for (int b = beg; b < end; b += clen, ++o, ++slot) {
+    for (int b = beg; b < end; b += (end - b > clen ? clen : end - b), ++o, ++slot) {
         Chunk c;
         c.beg = b;
         c.end = (end - b > clen) ? b + clen : end;

@@ -12,7 +12,8 @@
 //
 //   spmm_rows_v2     short rows; a lane group per row, lanes own output columns, no cross-lane
 //                    reduction -> bit-identical to the reference kernel   
-//   spmm_rows        the first version of the same (per-row fetch, no prefetch): A/B baseline
+//   spmm_rows        the first version of the same (per-row fetch, no prefetch): A/B baseline, only in the
+//                    -DMI_SPMM_ABLATE library (make -C hpc_amd/csrc ablate); not in the product
 //   spmm_chunks      medium rows as ONE exact segment each (straight to C) and hub rows as pieces
 //   spmm_reduce_chunks   ... whose partial sums are added left to right (deterministic; the only
 //                    place where the summation order differs from the reference)   (4.2)
@@ -127,6 +128,7 @@ __device__ __forceinline__ const float *b_row_ptr(const float *B, int64_t ldb, u
     return reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
 }
 
+#ifdef MI_SPMM_ABLATE   // first-generation rows kernel: built only into the A/B library (make ablate), never shipped
 // The fma chain of one segment [beg, end) of nonzeros for this lane's V
 // output columns.  Group-uniform control flow: all LPR lanes of a group see
 // the same beg/end.  The group fetches LPR (col, val) pairs with one
@@ -226,6 +228,8 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_rows(RowsArgs a)
         if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)r * a.ldc + col, acc);
     }
 }
+
+#endif  // MI_SPMM_ABLATE
 
 // ---- rows kernel v2: same arithmetic, software-pipelined over (row, chunk) items ----
 // v1 above serialises three memory round trips per row (row_ptr -> (col,val) -> B rows) and
@@ -367,13 +371,12 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
     if (nrows <= 0) return;
     // lane i of the group holds row_ptr[gbase + i], i = 0..nrows
     const int myptr = a.row_ptr[gbase + min(lig, nrows)];
-    unsigned f0 = 0, f1 = 0;
-    if (a.blk_flag) {
-        f0 = a.blk_flag[gbase >> 4];
-        f1 = a.blk_flag[(gbase + nrows - 1) >> 4];
-    }
+    // lane i of the group also holds the block-path ownership flag of ITS row gbase + i: a run of up to
+    // LPR - 1 rows can span five 16-row groups, each owned (or not) by the MFMA path independently
+    int myflag = 0;
+    if (a.blk_flag) myflag = a.blk_flag[(gbase + min(lig, nrows - 1)) >> 4];
     auto mine = [&](int ri, int rbeg, int rend) -> bool {
-        const unsigned f = (((gbase + ri) >> 4) == (gbase >> 4)) ? f0 : f1;
+        const int f = a.blk_flag ? group_bcast<LPR>(myflag, ri) : 0;
         return (rend - rbeg <= a.long_thr) && f == 0;
     };
 
@@ -576,9 +579,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // -> ds_write_b128 into the wave's LDS slice (row pitch N_slab+16 floats: the 4 k-rows of an MFMA
 // operand land on disjoint banks) -> per 4-k step one A-fragment dword and TILES x (ds_read_b32 +
 // MFMA).  The next batch's global loads are issued before the current batch's MFMAs.
-// ABL: timing-only ablations (cdna_hip_programming.md section 7, step 2): 2 = no B loads, 4 = no MFMA, 8 = no C stores.
-// Compile-time on purpose: as a run-time branch inside the MFMA loop it wrecked the schedule (5x slower).
-template <int TILES, bool WIDE, int ABL = 0>
+template <int TILES, bool WIDE>
 __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_blocks(BlockArgs a)
 {
     constexpr int NS = 16 * TILES;        // slab width in floats
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
             const int j = u * RPI + q_in;
             const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
             R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-            if (kb + j < L && !(ABL & 2)) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
+            if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -657,8 +658,7 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
 #pragma unroll
             for (int t = 0; t < TILES; ++t) {
                 const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-                if (!(ABL & 4)) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s], b, acc[t], 0, 0, 0);
-                else acc[t][0] += b * acur[s];  // ablation: keep the LDS read and the A value live
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s], b, acc[t], 0, 0, 0);
             }
         }
     }
@@ -680,15 +680,13 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
 #pragma unroll
             for (int q = 0; q < 4; ++q) lds[(4 * kq + q) * LDT + 16 * t + i16] = acc[h * EH + t][q];
         wave_lds_sync();
-        if (!(ABL & 8) || acc[0][0] == 12345.678f) {
 #pragma unroll
-            for (int it = 0; it < 16 / ERPI; ++it) {
-                const int row = it * ERPI + lane / ELPR;
-                const int c4 = 4 * (lane % ELPR);
-                const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
-                if (r0 + row >= a.row_lo && r0 + row < a.row_hi)
-                    __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4));
-            }
+        for (int it = 0; it < 16 / ERPI; ++it) {
+            const int row = it * ERPI + lane / ELPR;
+            const int c4 = 4 * (lane % ELPR);
+            const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
+            if (r0 + row >= a.row_lo && r0 + row < a.row_hi)
+                __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4));
         }
     }
 }

@@ -115,6 +115,9 @@ const char *mi_spmm_strerror(int code);
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
  *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel (8, 16, 32; default 32)
  *   "split_cols"          1 (default): up to 64 columns past the last full 256-column tile get their own launches
+ *   "tile_cols"           widest column tile of the rows / segment kernels: 256 (one row per wavefront), 128, 64, 32;
+ *                         0 = auto.  Tiles are swept one after the other, so this sets the B working set of a sweep
+ *                         (K x tile_cols x 4 bytes).  Scheduling only: results do not depend on it
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto
  *   "gpu_preprocess"      1 (default): segment table built on the device; 0: reference-style host loop
  *   "kernel"              1: per-row fetch (spmm_rows), 2: pipelined items (spmm_rows_v2, default)

@@ -4,6 +4,7 @@
 //   struct CSR                      PA4/workspace/include/util.h:120-129
 //   class SpMM (abstract)           PA4/workspace/include/spmm_base.h:8-46
 //   class SpMMOpt : public SpMM     PA4/workspace/include/spmm_opt.h:12-29  (the drop-in)
+//   class SpMMRef : public SpMM     PA4/workspace/include/spmm_ref.h:7-15   (exact-order configuration of the same library)
 //   int valid(float*,float*,int), int valid(int*,int*,int)   PA4/workspace/include/valid.h
 //   getCUDATime / getAverageTimeWithWarmUp                    PA4/workspace/include/util.h:131-151
 //
@@ -107,6 +108,43 @@ private:
     }
     mi_spmm_handle *h_ = nullptr;
     hipStream_t stream_ = nullptr;
+};
+
+// spmm_ref.h:7-15 / spmm_ref.cu:20-30 -- the course's reference operator.  The reference implements it with
+// spmm_kernel_ref (one thread per row, spmm_ref.cu:3-17); here it is the product library's EXACT-ORDER
+// configuration: every row, whatever its length, is one fma chain in stored order in the rows kernel (no row
+// splitting, no segment kernel, no MFMA block path), which is bit-identical to spmm_kernel_ref -- pinned by
+// tests/test_parity_gpu.py::test_reference_kernel_agrees_with_oracle_live and tests/test_fullsize_gpu.py against
+// the reference kernel itself.  So test/test_spmm.cu:33 (`new SpMMRef(g, kLen)`) compiles unchanged and
+// SpMMTest.validation compares SpMMOpt with SpMMRef on the device exactly as the reference does.
+class SpMMRef : public SpMM {
+public:
+    SpMMRef(int *dev_out_ptr, int *dev_out_idx, int out_num_v, int out_num_e, int out_feat_in)
+        : SpMM(dev_out_ptr, dev_out_idx, out_num_v, out_num_e, out_feat_in) {}
+    SpMMRef(CSR *g, int out_feat_in) : SpMM(g, out_feat_in) {}
+    ~SpMMRef() override
+    {
+        if (h_) (void)mi_spmm_destroy(h_);
+    }
+    void set_feat(int given_feat) override
+    {
+        SpMM::set_feat(given_feat);
+        if (h_) MI_CHECK(mi_spmm_set_feat(h_, given_feat));
+    }
+    void preprocess(float *vin, float *vout) override
+    {
+        if (!h_) {
+            MI_CHECK(mi_spmm_create(&h_, d_ptr, d_idx, d_val, num_v, num_v, num_e, feat_in));
+            MI_CHECK(mi_spmm_set_option(h_, "long_row_threshold", 1LL << 30));    // never split a row
+            MI_CHECK(mi_spmm_set_option(h_, "medium_row_threshold", 1LL << 30));  // every row stays in the rows kernel
+            MI_CHECK(mi_spmm_set_option(h_, "block_path", 0));
+        }
+        MI_CHECK(mi_spmm_preprocess(h_, vin, vout));
+    }
+    void run(float *vin, float *vout) override { MI_CHECK(mi_spmm_run(h_, vin, vout, nullptr)); }
+
+private:
+    mi_spmm_handle *h_ = nullptr;
 };
 
 #ifdef MI_SPMM_WITH_COMPARATOR

@@ -13,7 +13,8 @@
 // RUN/OK/PASSED) so the reference's plot.py regexes (plot.py:13-14) parse our logs: the first
 // `time =` of a block is the vendor library, the second is opt (test_spmm.cu:46-62).
 //
-// TEST INFRASTRUCTURE: the "SpMMRef" side of the validation is the CPU oracle
+// SpMMTest.validation compares SpMMOpt with SpMMRef on the device like the reference (test_spmm.cu:33-43).
+// TEST INFRASTRUCTURE: as a second check SpMMRef's result must equal the CPU oracle bit for bit
 // (oracle/liboracle.so, restating spmm_ref.cu:3-17) -- the product never links it.
 #define MI_SPMM_WITH_COMPARATOR
 #include "spmm_adapter.hpp"
@@ -168,29 +169,37 @@ static int failures = 0;
 
 static std::vector<int> h_ptr, h_idx;
 
-// test_spmm.cu:31-44
+// test_spmm.cu:31-44 -- SpMMOpt against SpMMRef on the device, as the reference does; then both against the CPU
+// restatement of spmm_kernel_ref (oracle) on the same device-generated inputs: SpMMRef must match it bit for bit.
 static bool validation(SpMMTest &t)
 {
-    SpMMOpt *spmmer = new SpMMOpt(t.g, kLen);
+    SpMM *spmmer_ref = new SpMMRef(t.g, kLen);
+    spmmer_ref->preprocess(t.p_in_feat_vec, t.p_out_feat_vec_ref);
+    SpMM *spmmer = new SpMMOpt(t.g, kLen);
     spmmer->preprocess(t.p_in_feat_vec, t.p_out_feat_vec);
-    MI_CHECK(hipMemset(t.p_out_feat_vec, 0, sizeof(float) * (size_t)kNumV * kLen));
+    const size_t nB = (size_t)kNumV * kLen;
+    MI_CHECK(hipMemset(t.p_out_feat_vec, 0, sizeof(float) * nB));
+    MI_CHECK(hipMemset(t.p_out_feat_vec_ref, 0, sizeof(float) * nB));
+    spmmer_ref->run(t.p_in_feat_vec, t.p_out_feat_vec_ref);
     spmmer->run(t.p_in_feat_vec, t.p_out_feat_vec);
     MI_CHECK(hipDeviceSynchronize());
-    // "SpMMRef": the CPU restatement of spmm_kernel_ref on the same device-generated inputs
-    const size_t nB = (size_t)kNumV * kLen;
-    std::vector<float> hB(nB), hVal((size_t)kNumE), hRef(nB);
-    MI_CHECK(hipMemcpy(hB.data(), t.p_in_feat_vec, nB * sizeof(float), hipMemcpyDeviceToHost));
-    MI_CHECK(hipMemcpy(hVal.data(), t.p_value, (size_t)kNumE * sizeof(float), hipMemcpyDeviceToHost));
-    oracle_spmm_omp(h_ptr.data(), h_idx.data(), hVal.data(), hB.data(), kLen, hRef.data(), kLen, kNumV, kLen, 0, kNumV);
-    MI_CHECK(hipMemcpy(t.p_out_feat_vec_ref, hRef.data(), nB * sizeof(float), hipMemcpyHostToDevice));
     const int bad = valid(t.p_out_feat_vec, t.p_out_feat_vec_ref, kNumV * kLen);
     int64_t ndiff = -1;
     float maxabs = 0.f;
     MI_CHECK(mi_spmm_count_bitdiff(t.p_out_feat_vec, t.p_out_feat_vec_ref, (int64_t)nB, &ndiff, &maxabs, nullptr));
     std::fprintf(stderr, "[tests/native/unit_tests.cpp:%d (TestBody)] bad = %d (int)  bitdiff = %lld  maxabs = %g\n", __LINE__, bad,
                  (long long)ndiff, maxabs);
+    // second check: the oracle (test infrastructure) on the same inputs -- SpMMRef is exact-order, so bit-identical
+    std::vector<float> hB(nB), hVal((size_t)kNumE), hRef(nB), hGot(nB);
+    MI_CHECK(hipMemcpy(hB.data(), t.p_in_feat_vec, nB * sizeof(float), hipMemcpyDeviceToHost));
+    MI_CHECK(hipMemcpy(hVal.data(), t.p_value, (size_t)kNumE * sizeof(float), hipMemcpyDeviceToHost));
+    MI_CHECK(hipMemcpy(hGot.data(), t.p_out_feat_vec_ref, nB * sizeof(float), hipMemcpyDeviceToHost));
+    oracle_spmm_omp(h_ptr.data(), h_idx.data(), hVal.data(), hB.data(), kLen, hRef.data(), kLen, kNumV, kLen, 0, kNumV);
+    const bool ref_exact = nB == 0 || std::memcmp(hGot.data(), hRef.data(), nB * sizeof(float)) == 0;
+    std::fprintf(stderr, "[tests/native/unit_tests.cpp:%d (TestBody)] ref_vs_oracle_bit_identical = %d (int)\n", __LINE__, ref_exact ? 1 : 0);
     delete spmmer;
-    return bad < kNumV * kLen / 10000 + 1;  // ASSERT_LT, test_spmm.cu:43
+    delete spmmer_ref;
+    return bad < kNumV * kLen / 10000 + 1 && ref_exact;  // ASSERT_LT, test_spmm.cu:43
 }
 
 // test_spmm.cu:46-53

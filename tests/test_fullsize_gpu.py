@@ -96,3 +96,127 @@ def test_permutation_matrix_is_a_row_gather(device):
     op.run(d_B, d_C)
     torch.cuda.synchronize()
     assert torch.equal(d_C, d_B[perm.long()])
+
+
+# ---- the other BASELINE configurations at full size (round-1 gap: only C1 was checked at M = 2^20) ----
+def _run_full(device, ptr, idx, vals, d_B, N, K, options=None):
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val = to_dev(device, ptr, idx, vals)
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+    for k, v in (options or {}).items():
+        op.set_option(k, v)
+    op.preprocess(d_B, d_C)
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    return d_ptr, d_idx, d_val, d_C, op
+
+
+def test_c2_power_law_full_size(device, oracle):
+    """BASELINE configs[2] at M = 2^20 (max 4096 nnz/row, N = 128): every split row and 4096 random rows against
+    the oracle evaluated in the documented piece order (bit-exact); unsplit rows bit-exact against the plain
+    oracle; the exact-order setting bit-identical to the reference's own kernel on the whole C."""
+    import torch
+    from hpc_amd.spmm import count_bitdiff
+
+    ptr, idx, vals, B, meta = synth.config("C2")
+    M, N = meta["M"], meta["N"]
+    assert M == 1 << 20 and meta["deg_max"] == 4096
+    (d_B,) = to_dev(device, B)
+    d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, M)
+    thr = op.get_option("long_row_threshold")
+    deg = np.diff(ptr)
+    split = np.nonzero(deg > thr)[0]
+    assert thr == 2048 and op.get_option("n_long_rows") == split.size > 0 and op.get_option("n_medium_rows") > 0
+    assert not torch.isnan(d_C).any()
+    g = np.random.Generator(np.random.Philox(key=[99, 2]))
+    rows = np.unique(np.concatenate([split, [0, M - 1], g.integers(0, M, 4096)]))
+    sp, si, sv = _sample_rows(ptr, idx, vals, rows)
+    got = d_C[rows.tolist()].cpu().numpy()
+    exp = oracle.spmm_chunked(sp, si, sv, B, thr, 256)
+    assert np.array_equal(bits(got), bits(exp))
+    plain = oracle.spmm_omp(sp, si, sv, B)
+    unsplit = deg[rows] <= thr
+    assert np.array_equal(bits(got[unsplit]), bits(plain[unsplit]))
+    _, sabs = oracle.spmm_f64(sp, si, sv, B)
+    assert (np.abs(got.astype(np.float64) - plain) <= 1e-5 * sabs + 1e-30).all()      # split rows: documented tolerance
+    # exact-order setting == the reference kernel, whole matrix
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    _, _, _, d_E, ope = _run_full(device, ptr, idx, vals, d_B, N, M, {"long_row_threshold": 1 << 30})
+    assert ope.get_option("n_long_rows") == 0
+    ndiff, maxabs = count_bitdiff(d_E, d_R)
+    assert ndiff == 0 and maxabs == 0.0
+    ndiff_auto, _ = count_bitdiff(d_C, d_R)                    # auto mode: only elements of split rows may differ
+    assert ndiff_auto <= split.size * N
+
+
+def test_c4_block_dense_full_size(device, oracle):
+    """BASELINE configs[4] at M = 2^20, N = 256 (151 M nonzeros, every 16-row group on the MFMA block path):
+    whole C bit-identical to the reference's own kernel; 4096 sampled rows bit-identical to the oracle."""
+    import torch
+    from hpc_amd.spmm import count_bitdiff
+
+    ptr, idx, vals, B, meta = synth.config("C4")
+    M, N = meta["M"], meta["N"]
+    assert M == 1 << 20 and N == 256
+    (d_B,) = to_dev(device, B)
+    d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, M)
+    assert op.get_option("n_block_groups") == M // 16
+    assert not torch.isnan(d_C).any()
+    g = np.random.Generator(np.random.Philox(key=[99, 4]))
+    rows = np.unique(np.concatenate([[0, 15, 16, M - 1], g.integers(0, M, 4096)]))
+    sp, si, sv = _sample_rows(ptr, idx, vals, rows)
+    assert np.array_equal(bits(d_C[rows.tolist()].cpu().numpy()), bits(oracle.spmm_omp(sp, si, sv, B)))
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    torch.cuda.synchronize()
+    ndiff, maxabs = count_bitdiff(d_C, d_R)
+    assert ndiff == 0 and maxabs == 0.0
+    # the rows kernel alone (block path off) gives the same bits
+    _, _, _, d_C0, op0 = _run_full(device, ptr, idx, vals, d_B, N, M, {"block_path": 0})
+    assert op0.get_option("n_block_groups") == 0
+    assert count_bitdiff(d_C0, d_R)[0] == 0
+
+
+def test_c3_one_gpu_leg_n1024_at_the_narrow_address_boundary(device, oracle):
+    """BASELINE configs[3]'s one-GPU leg: C1's CSR with N = 1024.  B is exactly 4 GiB, so the last byte of B sits
+    exactly at 2^32: the largest case the 32-bit-offset ("narrow") kernels take.  B is filled on the device
+    (4 GiB of host normals would take longer than the test); whole C against the reference's own kernel,
+    sampled rows against the oracle on the gathered B rows."""
+    import torch
+    from hpc_amd.spmm import count_bitdiff, fill_normal
+
+    ptr, idx = synth.csr_uniform(1 << 20, 16, 48)
+    vals = synth.make_values(idx.size)
+    M = K = 1 << 20
+    N = 1024
+    d_B = torch.empty(K * N, dtype=torch.float32, device=device)
+    fill_normal(d_B, seed=125, subsequence=3)
+    d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, K)
+    assert op.get_option("wide_addressing") == 0 and op.get_option("lanes_per_row") == 64
+    assert not torch.isnan(d_C).any()
+    g = np.random.Generator(np.random.Philox(key=[99, 3]))
+    rows = np.unique(np.concatenate([[0, M - 1], g.integers(0, M, 1024)]))
+    # rows whose columns include the very last B rows (the bytes next to 2^32)
+    last_users = np.nonzero(np.isin(idx, [K - 1, K - 2]))[0]
+    rows = np.unique(np.concatenate([rows, np.searchsorted(ptr, last_users, side="right") - 1]))
+    sp, si, sv = _sample_rows(ptr, idx, vals, rows)
+    cols, inv = np.unique(si, return_inverse=True)
+    Bsub = d_B.view(K, N)[torch.from_numpy(cols.astype(np.int64)).to(device)].cpu().numpy()
+    exp = oracle.spmm_omp(sp, inv.astype(np.int32), sv, Bsub)
+    assert np.array_equal(bits(d_C[rows.tolist()].cpu().numpy()), bits(exp))
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    torch.cuda.synchronize()
+    ndiff, maxabs = count_bitdiff(d_C, d_R)
+    assert ndiff == 0 and maxabs == 0.0

@@ -34,11 +34,10 @@ def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
     M, K = 777, 513
     ptr, idx, vals, B = _rand_case(M, K, N, 0, 70, seed=100 + N)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
-    for kernel in (1, 2):
-        C, op = run_spmm(device, ptr, idx, vals, B, options={"kernel": kernel})
-        assert not np.isnan(C).any(), "output not fully overwritten"
-        assert np.array_equal(bits(C), bits(ref)), f"kernel {kernel}: {(bits(C) != bits(ref)).sum()} elements differ"
-        assert op.get_option("vector_width") == (4 if N >= 4 else 1)   # 16 B per lane at any width >= 4 (dword-aligned dwordx4)
+    C, op = run_spmm(device, ptr, idx, vals, B)
+    assert not np.isnan(C).any(), "output not fully overwritten"
+    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).sum()} elements differ"
+    assert op.get_option("vector_width") == (4 if N >= 4 else 1)   # 16 B per lane at any width >= 4 (dword-aligned dwordx4)
 
 
 @pytest.mark.parametrize("block_threads", [64, 128, 256])
@@ -47,20 +46,18 @@ def test_bitwise_vs_oracle_over_feature_widths(device, oracle, N):
 def test_bitwise_over_tuning_knobs(device, oracle, block_threads, pol, N):
     ptr, idx, vals, B = _rand_case(2000, 2000, N, 0, 90, seed=7)
     ref = oracle.spmm_omp(ptr, idx, vals, B)
-    for rpb, xcd, kernel in ((0, 1, 1), (16, 0, 1), (1000, 1, 1), (0, 1, 2), (8, 0, 2), (1000, 0, 2)):
+    for rpb, xcd in ((0, 1), (8, 0), (16, 1), (1000, 0), (1000, 1)):
         C, _ = run_spmm(device, ptr, idx, vals, B, options={
-            "block_threads": block_threads, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd,
-            "kernel": kernel})
-        assert np.array_equal(bits(C), bits(ref)), (rpb, xcd, kernel)
+            "block_threads": block_threads, "nt_store": pol & 1, "nt_stream": (pol >> 1) & 1, "rows_per_block": rpb, "xcd_remap": xcd})
+        assert np.array_equal(bits(C), bits(ref)), (rpb, xcd)
 
 
 def test_edge_shapes(device, oracle):
     # M = 1; all rows empty; a single nonzero; K != M; nnz = 0
     for (M, K, N, lo, hi, seed) in [(1, 1, 4, 1, 1, 1), (5, 9, 8, 0, 0, 2), (1, 300, 128, 200, 200, 3), (300, 7, 16, 0, 7, 4), (64, 64, 128, 64, 64, 5)]:
         ptr, idx, vals, B = _rand_case(M, K, N, lo, hi, seed)
-        for kernel in (1, 2):
-            C, _ = run_spmm(device, ptr, idx, vals, B, options={"kernel": kernel})
-            assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (M, K, N, kernel)
+        C, _ = run_spmm(device, ptr, idx, vals, B)
+        assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (M, K, N)
 
 
 def test_empty_matrix_and_zero_width(device):
@@ -84,7 +81,7 @@ def test_overwrite_and_idempotent(device, oracle):
     from hpc_amd import CSR, SpMMOpt
 
     ptr, idx, vals, B = _rand_case(3000, 3000, 64, 0, 600, seed=9)   # includes split rows (> 512)
-    ptr[-1] == idx.size
+    assert ptr[-1] == idx.size
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((3000, 64), 1e30, dtype=torch.float32, device=device)
     op = SpMMOpt(CSR(3000, idx.size, d_ptr, d_idx, d_val), 64)
@@ -350,6 +347,42 @@ def test_block_path_with_row_panels_and_pitches(device, oracle):
     assert torch.isnan(wide[:, :128]).all()
 
 
+@pytest.mark.parametrize("N", [32, 128, 256])
+@pytest.mark.parametrize("rpb", [0, 16, 40, 1000])
+def test_block_groups_with_long_lane_group_runs(device, oracle, N, rpb):
+    """A lane group of the rows kernel may own up to LPR - 1 = 63 consecutive rows ("rows_per_block" large), i.e. up
+    to five 16-row groups, each of which is or is not owned by the MFMA block path: ownership is looked up per row.
+    (Round-1 defect: only the first and the last group's flag were sampled -- middle rows were skipped or computed
+    twice.)  Shared-list groups interleaved with ragged groups, every row NaN-poisoned beforehand."""
+    ptr, idx, vals, B, kinds = _shared_list_case(120, 1500, N, seed=5150 + N, lens=[12, 40, 9, 64, 33])
+    ref = oracle.spmm_omp(ptr, idx, vals, B)
+    C, op = run_spmm(device, ptr, idx, vals, B, options={"rows_per_block": rpb, "long_row_threshold": 2048})
+    assert op.get_option("n_block_groups") == sum(1 for k, _ in kinds if k == 0) > 20
+    assert sum(1 for k, _ in kinds if k != 0) > 20          # ... next to groups the rows kernel owns
+    assert not np.isnan(C).any(), f"{int(np.isnan(C).any(axis=1).sum())} rows left unwritten"
+    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).any(axis=1).sum()} rows differ"
+
+
+def test_product_library_refuses_ablation_options(device):
+    """The first-generation rows kernel and the timing-only block-kernel builds exist only in the A/B library
+    (make -C hpc_amd/csrc ablate); the shipped ABI has no option that can produce a wrong C."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd.spmm import MiSpmmError
+
+    d_ptr = torch.zeros(2, dtype=torch.int32, device=device)
+    e = torch.zeros(0, dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(1, 0, d_ptr, torch.zeros(0, dtype=torch.int32, device=device), e), 8)
+    for key, v in (("block_ablate", 2), ("kernel", 1)):
+        with pytest.raises(MiSpmmError) as ei:
+            op.set_option(key, v)
+        assert ei.value.code == -5          # MI_SPMM_EUNSUPPORTED
+    with pytest.raises(MiSpmmError) as ei:
+        op.set_option("long_row_chunk", 1 << 21)
+    assert ei.value.code == -1              # MI_SPMM_EINVAL: piece length beyond what the int32 plan arithmetic allows
+    op.set_option("kernel", 2)
+
+
 @pytest.mark.parametrize("N", [32, 128, 36])
 def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N):
     """mi_spmm_run_rows on an arbitrary range: exactly those rows of C are written -- short rows, medium rows
@@ -514,6 +547,8 @@ def test_native_harness_end_to_end(device, tmp_path):
         assert len(times) == 2 and all(0 < t < 1 for t in times)
         m = re.search(r"bad = (\d+) \(int\)\s+bitdiff = (\d+)", r.stderr)
         assert int(m.group(1)) < 30000 * n_len // 10000 + 1
+        # SpMMRef (include/spmm_adapter.hpp: the library's exact-order configuration) == the CPU oracle, bit for bit
+        assert "ref_vs_oracle_bit_identical = 1 (int)" in r.stderr
         assert os.path.exists(tmp_path / "syn.graph.ptrdump") and os.path.exists(tmp_path / "syn.graph.edgedump")
 
 
@@ -591,7 +626,7 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
         ldb = N + int(g.choice([0, 0, 4, 5, 64]))
         ldc = N + int(g.choice([0, 0, 4, 3, 128]))
         Bp = synth.normal_f32(K * ldb, 9000 + case).reshape(K, ldb)
-        opts = {"kernel": int(g.choice([1, 2])), "medium_row_threshold": int(g.choice([0, 1, 5, 64, 1000])),
+        opts = {"medium_row_threshold": int(g.choice([0, 1, 5, 64, 1000])),
                 "long_row_threshold": int(g.choice([6, 40, 2048])), "long_row_chunk": int(g.choice([3, 16, 256])),
                 "block_path": int(g.choice([0, 1])), "segment_unroll": int(g.choice([8, 16, 32]))}
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
@@ -629,7 +664,7 @@ def test_special_values_all_paths(device, oracle):
     vals[g.integers(0, vals.size, 400)] = special[g.integers(0, special.size, 400)]
     B.reshape(-1)[g.integers(0, B.size, 4000)] = special[g.integers(0, special.size, 4000)]
     ref = oracle.spmm_chunked(ptr, idx, vals, B, 256, 64)
-    for opts in ({"kernel": 2}, {"kernel": 1}, {"block_path": 0}):
+    for opts in ({}, {"block_path": 0}, {"rows_per_block": 1000}):
         o = {"long_row_threshold": 256, "long_row_chunk": 64}
         o.update(opts)
         C, op = run_spmm(device, ptr, idx, vals, B, options=o)
@@ -724,10 +759,10 @@ def test_wide_addressing_variants(device, oracle):
     assert op.get_option("wide_addressing") == 1 and op.get_option("vector_width") == 4
     exp = oracle.spmm_chunked(ptr, idx, vals, Bs, 256, 256)
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
-    for kernel in (1, 2):
-        op.set_option("kernel", kernel)
+    for rpb in (0, 1000):                     # long lane-group runs through the wide variants too
+        op.set_option("rows_per_block", rpb)
         d_C.fill_(float("nan"))
         op.run_ld(d_B, ldb, d_C, N)
         torch.cuda.synchronize()
-        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)), kernel
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)), rpb
     del d_B
