@@ -61,12 +61,21 @@ struct mi_spmm_handle {
     int32_t *d_blk_groups;
     int32_t n_blk_groups;
     int64_t n_rows_for_rows_kernel;  // rows neither split nor owned by the block path
+    // block path, run time: pieces of the groups' column lists, grouped into items, per pass (spmm_kernels.hpp)
+    int64_t block_share;       // most pieces per item (1 = no sharing; default 2)
+    int64_t block_max_pieces;  // most pieces a group's list is cut into = most passes (1 = never cut)
+    int64_t block_run_min;     // shortest run worth a piece of its own
+    BlockItem *d_blk_items;
+    BlockPiece *d_blk_pieces;
+    int32_t n_blk_items, n_blk_pieces, n_blk_passes, n_blk_shared_items;
+    struct { int32_t off, n; } blk_launch[kMaxPieces][2];   // [pass][0: single-piece items, 1: shared items]
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
 // Pieces of a split row: the plan builders step through a row in int32; a piece length far beyond any row
 // that can be split usefully would overflow `b + clen`.
 static const int64_t kMaxLongChunk = 1 << 20;
+static const int kMaxShare = 2;   // widest item the block kernels are instantiated for (spmm_block_items<.., G, ..>)
 
 static bool good(const mi_spmm_handle *h) { return h && h->magic == kMagic; }
 
@@ -77,6 +86,12 @@ static void free_plan(mi_spmm_handle *h)
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_blk_flag) (void)hipFree(h->d_blk_flag);
     if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
+    if (h->d_blk_items) (void)hipFree(h->d_blk_items);
+    if (h->d_blk_pieces) (void)hipFree(h->d_blk_pieces);
+    h->d_blk_items = nullptr;
+    h->d_blk_pieces = nullptr;
+    h->n_blk_items = h->n_blk_pieces = h->n_blk_passes = h->n_blk_shared_items = 0;
+    std::memset(h->blk_launch, 0, sizeof(h->blk_launch));
     h->d_blk_flag = nullptr;
     h->d_blk_groups = nullptr;
     h->n_blk_groups = 0;
@@ -92,6 +107,107 @@ static void free_plan(mi_spmm_handle *h)
 // a multiple of 32 qualifies, with the widest slab that divides it.
 static int block_slab_width(int32_t N) { return N <= 0 ? 0 : (N % 256 == 0 ? 256 : N % 128 == 0 ? 128 : N % 64 == 0 ? 64 : N % 32 == 0 ? 32 : 0); }
 static bool block_path_shape_ok(int32_t N) { return block_slab_width(N) != 0; }
+
+// Block path, second half of preprocess: the qualifying groups (d_blk_groups, either plan builder) are cut into
+// pieces on the device (analyze_group_runs: one wave per group, O(nnz / 16) reads); the pieces -- a few per
+// group -- come back to the host, which orders every pass's pieces by first column and forms the items:
+// run pieces with the same first column share their B rows (longest first, at most block_share per item, every
+// shared length a multiple of the MFMA k-step so that no piece ends inside a step).  O(groups log groups) on
+// the host, once per preprocess; untimed by the reference's harness (test_spmm.cu:58).
+static int build_block_items(mi_spmm_handle *h)
+{
+    const int32_t ng = h->n_blk_groups;
+    if (ng <= 0) return MI_SPMM_OK;
+    GroupPieces *d_gp = nullptr;
+    if (hipMalloc((void **)&d_gp, (size_t)ng * sizeof(GroupPieces)) != hipSuccess) return MI_SPMM_ENOMEM;
+    hipLaunchKernelGGL(analyze_group_runs, dim3((unsigned)((ng + 3) / 4)), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx,
+                       h->d_blk_groups, ng, (int32_t)h->block_max_pieces, (int32_t)h->block_run_min, d_gp);
+    hipError_t e = hipGetLastError();
+    std::vector<GroupPieces> gp((size_t)ng);
+    std::vector<int32_t> groups((size_t)ng);
+    if (e == hipSuccess) e = hipMemcpy(gp.data(), d_gp, (size_t)ng * sizeof(GroupPieces), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(groups.data(), h->d_blk_groups, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_gp);
+    if (e != hipSuccess) return (int)e;
+
+    struct Key { int32_t col, len, gi, ord; bool shareable; };
+    std::vector<BlockItem> items;
+    std::vector<BlockPiece> pieces;
+    int32_t n_pass = 0, n_shared = 0;
+    // shared items need the two-piece kernels, which exist for 256- and 128-column slabs (N % 128 == 0)
+    const int share = block_slab_width(h->feat) >= 128 ? (int)h->block_share : 1;
+    std::vector<Key> keys;
+    std::vector<BlockItem> singles, shared;
+    for (int pass = 0; pass < kMaxPieces; ++pass) {
+        keys.clear();
+        for (int32_t gi = 0; gi < ng; ++gi) {
+            const GroupPieces &g = gp[(size_t)gi];
+            if (g.n <= pass) continue;
+            Key k;
+            const int32_t c = g.c0[pass];
+            k.col = c >= 0 ? c : -1 - c;
+            k.len = g.len[pass];
+            k.gi = gi;
+            k.ord = pass;
+            k.shareable = c >= 0 && (g.len[pass] % 4) == 0 && share > 1;
+            keys.push_back(k);
+        }
+        if (keys.empty()) break;
+        n_pass = pass + 1;
+        // by first column; among equals the shareable ones together, longest first; ties in group order (deterministic)
+        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+            if (a.col != b.col) return a.col < b.col;
+            if (a.shareable != b.shareable) return a.shareable > b.shareable;
+            if (a.len != b.len) return a.len > b.len;
+            return a.gi < b.gi;
+        });
+        singles.clear();
+        shared.clear();
+        size_t i = 0;
+        while (i < keys.size()) {
+            size_t j = i + 1;
+            if (keys[i].shareable)
+                while (j < keys.size() && j - i < (size_t)share && keys[j].shareable && keys[j].col == keys[i].col) ++j;
+            BlockItem it;
+            it.first = (int32_t)pieces.size();
+            it.m = (int32_t)(j - i);
+            const GroupPieces &g0 = gp[(size_t)keys[i].gi];
+            it.c0 = g0.c0[pass];
+            it.len_max = keys[i].len;
+            for (size_t q = i; q < j; ++q) {
+                const GroupPieces &g = gp[(size_t)keys[q].gi];
+                BlockPiece p;
+                p.group = groups[(size_t)keys[q].gi];
+                p.k0 = g.k0[pass];
+                p.len = g.len[pass];
+                p.flags = (pass > 0 ? kPieceCarryIn : 0) | (pass + 1 < g.n ? kPieceCarryOut : 0);
+                pieces.push_back(p);
+            }
+            (it.m > 1 ? shared : singles).push_back(it);
+            i = j;
+        }
+        h->blk_launch[pass][0].off = (int32_t)items.size();
+        h->blk_launch[pass][0].n = (int32_t)singles.size();
+        items.insert(items.end(), singles.begin(), singles.end());
+        h->blk_launch[pass][1].off = (int32_t)items.size();
+        h->blk_launch[pass][1].n = (int32_t)shared.size();
+        items.insert(items.end(), shared.begin(), shared.end());
+        n_shared += (int32_t)shared.size();
+    }
+    if (items.empty()) return MI_SPMM_OK;
+    if (hipMalloc((void **)&h->d_blk_items, items.size() * sizeof(BlockItem)) != hipSuccess ||
+        hipMalloc((void **)&h->d_blk_pieces, pieces.size() * sizeof(BlockPiece)) != hipSuccess)
+        return MI_SPMM_ENOMEM;
+    e = hipMemcpy(h->d_blk_items, items.data(), items.size() * sizeof(BlockItem), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_blk_pieces, pieces.data(), pieces.size() * sizeof(BlockPiece), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+    h->n_blk_items = (int32_t)items.size();
+    h->n_blk_pieces = (int32_t)pieces.size();
+    h->n_blk_passes = n_pass;
+    h->n_blk_shared_items = n_shared;
+    h->ws_bytes += items.size() * sizeof(BlockItem) + pieces.size() * sizeof(BlockPiece);
+    return MI_SPMM_OK;
+}
 
 // preprocess with no host pass over the rows: column check, block detection, classification, scans,
 // segment emission and the length sort all run on the device; one small copy comes back.
@@ -153,6 +269,10 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         h->ws_bytes = pb;
     }
     h->ws_bytes += (size_t)h->n_chunks * sizeof(Chunk) + (size_t)h->n_long * sizeof(LongRow);
+    {
+        const int brc = build_block_items(h);
+        if (brc != 0) { free_plan(h); return brc; }
+    }
     lap(4);
     h->prepared = true;
     h->preprocess_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -217,6 +337,9 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->nt_stream = 0;      // (col,val) fetches straddle lines: nt would drop the line before its other half is used
     h->block_path = 1;
     h->block_min_len = 8;
+    h->block_share = 2;
+    h->block_max_pieces = kMaxPieces;
+    h->block_run_min = 32;
     h->kernel = 2;
     h->gpu_preprocess = 1;
     h->block_threads = 256;
@@ -273,6 +396,9 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
     else if (k == "block_path") { h->block_path = v ? 1 : 0; free_plan(h); }
     else if (k == "block_min_len") { if (v < 1) return MI_SPMM_EINVAL; h->block_min_len = v; free_plan(h); }
+    else if (k == "block_share") { if (v < 1 || v > kMaxShare) return MI_SPMM_EINVAL; h->block_share = v; free_plan(h); }
+    else if (k == "block_max_pieces") { if (v < 1 || v > kMaxPieces) return MI_SPMM_EINVAL; h->block_max_pieces = v; free_plan(h); }
+    else if (k == "block_run_min") { if (v < 1) return MI_SPMM_EINVAL; h->block_run_min = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
 }
@@ -307,6 +433,13 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "wide_addressing") *value = h->last_wide;
     else if (k == "n_block_groups") *value = h->n_blk_groups;
     else if (k == "block_min_len") *value = h->block_min_len;
+    else if (k == "block_share") *value = h->block_share;
+    else if (k == "block_max_pieces") *value = h->block_max_pieces;
+    else if (k == "block_run_min") *value = h->block_run_min;
+    else if (k == "n_block_items") *value = h->n_blk_items;
+    else if (k == "n_block_pieces") *value = h->n_blk_pieces;
+    else if (k == "n_block_passes") *value = h->n_blk_passes;
+    else if (k == "n_block_shared_items") *value = h->n_blk_shared_items;
     else if (k == "preprocess_us") *value = (int64_t)h->preprocess_us;
     else if (k == "pre_d2h_us") *value = (int64_t)h->phase_us[0];
     else if (k == "pre_colcheck_us") *value = (int64_t)h->phase_us[1];
@@ -496,6 +629,10 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         }
         h->ws_bytes = cb + lb + pb;
     }
+    {
+        const int brc = build_block_items(h);
+        if (brc != 0) { free_plan(h); return brc; }
+    }
     lap(4, tp);
     h->prepared = true;
     h->preprocess_us =
@@ -592,18 +729,19 @@ void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s, in
     }
 }
 
-template <bool WIDE>
-void launch_blocks_w(int slab, const BlockArgs &a, dim3 grid, hipStream_t s)
+template <int G, bool WIDE>
+void launch_block_items_g(int slab, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
-    if (slab == 32) hipLaunchKernelGGL((spmm_blocks<2, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (slab == 64) hipLaunchKernelGGL((spmm_blocks<4, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (slab == 128) hipLaunchKernelGGL((spmm_blocks<8, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else hipLaunchKernelGGL((spmm_blocks<16, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    // shared items (G > 1) exist only for slabs of 256 or 128 columns (N % 128 == 0); narrower N runs every item alone
+    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<16, G, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<8, G, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<4, 1, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<2, 1, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
 }
-void launch_blocks(int slab, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
+void launch_block_items(int slab, int g, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
-    if (wide) launch_blocks_w<true>(slab, a, grid, s);
-    else launch_blocks_w<false>(slab, a, grid, s);
+    if (g > 1) { if (wide) launch_block_items_g<2, true>(slab, a, grid, s); else launch_block_items_g<2, false>(slab, a, grid, s); }
+    else { if (wide) launch_block_items_g<1, true>(slab, a, grid, s); else launch_block_items_g<1, false>(slab, a, grid, s); }
 }
 
 // auto: see profiles/r02_wide_n_tiles.txt
@@ -707,7 +845,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
                              ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
     if (blocks_on && launch_blocks_here) {
         BlockArgs ba;
-        ba.groups = h->d_blk_groups;
+        ba.pieces = h->d_blk_pieces;
         ba.row_ptr = h->d_ptr;
         ba.col_idx = h->d_idx;
         ba.vals = h->d_val;
@@ -715,17 +853,23 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ba.C = full.C;
         ba.ldb = ldb;
         ba.ldc = ldc;
-        ba.n_groups = h->n_blk_groups;
         ba.N = full.N;
         ba.remap = remap_blocks ? 1 : 0;
         ba.row_lo = row_begin;
         ba.row_hi = row_end;
-        {
-            const int slab = block_slab_width(full.N), slabs = full.N / slab;
-            dim3 bgrid((h->n_blk_groups + 3) / 4, slabs);
-            launch_blocks(slab, wide_full, ba, bgrid, s);
+        const int slab = block_slab_width(full.N), slabs = full.N / slab;
+        // pass p continues the fma chains pass p-1 left in C: stream order is the dependency
+        for (int pass = 0; pass < h->n_blk_passes; ++pass) {
+            for (int cls = 1; cls >= 0; --cls) {
+                const int32_t n = h->blk_launch[pass][cls].n;
+                if (n == 0) continue;
+                ba.items = h->d_blk_items + h->blk_launch[pass][cls].off;
+                ba.n_items = n;
+                dim3 bgrid((unsigned)((n + 3) / 4), slabs);
+                launch_block_items(slab, cls ? 2 : 1, wide_full, ba, bgrid, s);
+                ++launches;
+            }
         }
-        ++launches;
     }
 
     RowsArgs a;

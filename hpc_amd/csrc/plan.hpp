@@ -22,8 +22,6 @@ struct PlanOut {
 // d_blk_flag: per 16-row group, 1 = block path owns it (nullable).  col_bad: device flag written
 // by csr_check_cols earlier on the same (null) stream; read back with the same single copy.
 // mthr: medium threshold, 0 = auto (resolved on the device from the longest row, returned in PlanOut::mthr).
-// d_col_idx is only read to order the block groups by their first column (cache locality of the
-// shared B rows; scheduling only, never arithmetic).
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
                    const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out);
 

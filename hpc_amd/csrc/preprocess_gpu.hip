@@ -133,15 +133,6 @@ struct DevBuf {   // temporary from the stream-ordered pool (hipMalloc/hipFree c
 
 #define PLAN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (e_ == hipErrorOutOfMemory) ? MI_SPMM_ENOMEM : (int)e_; } while (0)
 
-__global__ __launch_bounds__(kBlockThreads) void group_first_col(const int32_t *__restrict__ row_ptr,
-                                                                const int32_t *__restrict__ col_idx,
-                                                                const int32_t *__restrict__ groups, int32_t n,
-                                                                uint32_t *__restrict__ keys)
-{
-    const int i = (int)(blockIdx.x * (unsigned)kBlockThreads + threadIdx.x);
-    if (i < n) keys[i] = (uint32_t)col_idx[row_ptr[groups[i] << 4]];
-}
-
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
                    const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out)
 {
@@ -201,22 +192,10 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     out->n_medium = host.n_chunks - host.n_slots;
     if (d_blk_flag && host.st.n_groups_selected > 0) {
         out->n_blk_groups = host.st.n_groups_selected;
-        // Block groups in order of their first column: groups that share (or neighbour) B rows run at
-        // about the same time on the same XCD, so the shared rows are fetched from HBM once.
+        // the qualifying groups in row order; build_block_items (mi_spmm.hip) cuts them into pieces and orders those
         const int ng = out->n_blk_groups;
-        DevBuf k_in, k_out, stmp;
         PLAN_TRY(hipMalloc((void **)&out->d_blk_groups, (size_t)ng * sizeof(int32_t)));
-        PLAN_TRY(k_in.alloc((size_t)ng * sizeof(uint32_t)));
-        PLAN_TRY(k_out.alloc((size_t)ng * sizeof(uint32_t)));
-        hipLaunchKernelGGL(group_first_col, dim3((unsigned)((ng + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads),
-                           0, 0, d_row_ptr, d_col_idx, groups.as<int32_t>(), ng, k_in.as<uint32_t>());
-        PLAN_TRY(hipGetLastError());
-        size_t gb = 0;
-        PLAN_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, gb, k_in.as<uint32_t>(), k_out.as<uint32_t>(),
-                                                    groups.as<int32_t>(), out->d_blk_groups, ng));
-        PLAN_TRY(stmp.alloc(gb));
-        PLAN_TRY(hipcub::DeviceRadixSort::SortPairs(stmp.p, gb, k_in.as<uint32_t>(), k_out.as<uint32_t>(),
-                                                    groups.as<int32_t>(), out->d_blk_groups, ng));
+        PLAN_TRY(hipMemcpyAsync(out->d_blk_groups, groups.p, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToDevice, 0));
         PLAN_TRY(hipStreamSynchronize(0));
     }
     if (host.n_chunks > 0) {

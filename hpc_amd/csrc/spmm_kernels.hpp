@@ -544,8 +544,20 @@ __global__ __launch_bounds__(kBlockThreads) void detect_row_blocks(const int32_t
     if (lane == 0) flag[g] = qualifies ? 1 : 0;
 }
 
+// ---- block path, run time: items of up to G pieces that share their B rows ------------------------
+// preprocess cuts every qualifying group's column list into PIECES (plan_types.hpp): maximal runs of
+// consecutive columns when the list is a few long runs, otherwise the whole list.  Piece p of a group is
+// processed in pass p (one launch set per pass, in stream order): pass 0 starts the group's fma chains from
+// +0, pass p > 0 CONTINUES them from the 16 x N tile pass p-1 left in C -- the accumulator of an f32 MFMA
+// chain is an ordinary f32, so storing it and loading it back changes no bit and the k order of every output
+// element is still the stored order.  Why bother: inside one pass the pieces are sorted by their first column
+// and pieces that are the same run [c0, c0+len) of different groups form one ITEM: its B rows are staged
+// through LDS once and feed every piece's MFMAs (reuse 16*m rows per B row instead of 16), and neighbouring
+// items touch neighbouring B rows on one XCD.  A group's second run no longer drags a random B range into
+// the sweep of its first run's neighbourhood.
 struct BlockArgs {
-    const int32_t *groups;   // compacted list of qualifying group indices
+    const BlockItem *items;
+    const BlockPiece *pieces;
     const int32_t *row_ptr;
     const int32_t *col_idx;
     const float *vals;
@@ -553,10 +565,10 @@ struct BlockArgs {
     float *C;
     int64_t ldb;
     int64_t ldc;
-    int32_t n_groups;
+    int32_t n_items;
     int32_t N;
-    int32_t remap;           // 1: XCD remap of blockIdx.x (the group list is ordered by first column)
-    int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are not stored; groups wholly outside are skipped
+    int32_t remap;           // 1: XCD remap of blockIdx.x (the item list is ordered by first column)
+    int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are neither loaded nor stored; pieces wholly outside are skipped
 };
 
 typedef float float4a __attribute__((ext_vector_type(4)));
@@ -571,16 +583,19 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave per 16-row group and 16*TILES-column slab (blockIdx.y = slab).
+// One wave per item and 16*TILES-column slab (blockIdx.y = slab); G = most pieces an item of this launch holds.
 //   v_mfma_f32_16x16x4_f32: A lane l = A[i = l&15][k = l>>4], B lane l = B[k = l>>4][j = l&15],
 //   D reg q of lane l = D[row 4*(l>>4)+q][col l&15]; the result is a k-ordered fp32 fma chain,
 //   so with k ascending per output element the block path is bit-identical to the rows path.
 // Per batch of KT k-rows: 8 x global_load_dwordx4 (8 KiB of B, full rows, coalesced) -> registers
 // -> ds_write_b128 into the wave's LDS slice (row pitch N_slab+16 floats: the 4 k-rows of an MFMA
-// operand land on disjoint banks) -> per 4-k step one A-fragment dword and TILES x (ds_read_b32 +
-// MFMA).  The next batch's global loads are issued before the current batch's MFMAs.
-template <int TILES, bool WIDE>
-__global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_blocks(BlockArgs a)
+// operand land on disjoint banks) -> per 4-k step ONE ds_read_b32 per tile feeding up to G MFMAs (one per
+// piece, each with its own A fragment and accumulators).  The next batch's global loads are issued before
+// the current batch's MFMAs.  Pieces of an item are ordered longest first and every shared piece's length
+// is a multiple of 4, so at any k-step the first `nact` pieces are active and no step is partial for a
+// piece that is not the longest (a partial step multiplies zero-filled B rows by zero A values: exact no-op).
+template <int TILES, int G, bool WIDE>
+__global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) void spmm_block_items(BlockArgs a)
 {
     constexpr int NS = 16 * TILES;        // slab width in floats
     constexpr int LPRB = NS / 4;          // lanes per B row (16 B each)
@@ -594,101 +609,311 @@ __global__ __launch_bounds__(kBlockThreads, (TILES >= 4 ? 4 : 3)) void spmm_bloc
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vblk = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int gi = vblk * 4 + wave;
-    if (gi >= a.n_groups) return;
+    const int ii = vblk * 4 + wave;
+    if (ii >= a.n_items) return;          // wave-uniform (the kernel has no workgroup barrier)
     float *lds = lds_all + wave * (KT * SLD);
-    const int g = a.groups[gi];
-    const int r0 = g << 4;
-    if (r0 + 16 <= a.row_lo || r0 >= a.row_hi) return;   // wave-uniform (the kernel has no workgroup barrier)
     const int i16 = lane & 15, kq = lane >> 4;
     const int slab0 = (int)blockIdx.y * NS;
-
-    const int p0 = __builtin_amdgcn_readfirstlane(a.row_ptr[r0]);
-    const int L = __builtin_amdgcn_readfirstlane(a.row_ptr[r0 + 1]) - p0;
-    const int my_row_start = a.row_ptr[r0 + i16];
-
     const int q_in = lane / LPRB;                  // which of the RPI rows of a load this lane serves
     const int colv = slab0 + 4 * (lane % LPRB);    // first of this lane's 4 columns
     const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colv * 4u;
 
-    float4a acc[TILES];
+    const BlockItem item = a.items[ii];
+    const int m = __builtin_amdgcn_readfirstlane(item.m);
+    const int first = __builtin_amdgcn_readfirstlane(item.first);
+    const int c0 = __builtin_amdgcn_readfirstlane(item.c0);   // >= 0: the pieces are the column run c0, c0+1, ...; < 0: a column list
+    int pg[G], pk0[G], plen[G], pfl[G];
+    bool inr[G];
+    int n_in = 0;
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) acc[t] = (float4a){0.f, 0.f, 0.f, 0.f};
-
-    float4v R[LOADS];
-    float af[KS];
-
-    // column indices run one batch ahead of the B rows they address (cj_next holds batch kb's indices
-    // when prefetch(kb) is called), so a prefetch is one memory round trip, not two dependent ones
-    int cj_next = (lane < KT && lane < L) ? a.col_idx[p0 + lane] : 0;
-    auto prefetch = [&](int kb) {
-        const int cj = cj_next;
-        const int kk = kb + KT + lane;
-        cj_next = (lane < KT && kk < L) ? a.col_idx[p0 + kk] : 0;
-#pragma unroll
-        for (int u = 0; u < LOADS; ++u) {
-            const int j = u * RPI + q_in;
-            const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
-            R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-            if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
+    for (int j = 0; j < G; ++j) {
+        pg[j] = pk0[j] = plen[j] = pfl[j] = 0;
+        inr[j] = false;
+        if (j < m) {
+            const BlockPiece p = a.pieces[first + j];
+            pg[j] = __builtin_amdgcn_readfirstlane(p.group);
+            pk0[j] = __builtin_amdgcn_readfirstlane(p.k0);
+            plen[j] = __builtin_amdgcn_readfirstlane(p.len);
+            pfl[j] = __builtin_amdgcn_readfirstlane(p.flags);
+            inr[j] = !((pg[j] << 4) + 16 <= a.row_lo || (pg[j] << 4) >= a.row_hi);
+            n_in += inr[j] ? 1 : 0;
         }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int k = kb + 4 * s + kq;
-            af[s] = (k < L) ? a.vals[my_row_start + k] : 0.f;
-        }
-    };
+    }
+    if (n_in == 0) return;
+    // every piece inside the row range (always, unless the caller runs row panels): one shared sweep.
+    // Otherwise the in-range pieces are swept one at a time.
+    const bool together = (n_in == m);
+    const int nrep = together ? 1 : m;
 
-    prefetch(0);
-    for (int kb = 0; kb < L; kb += KT) {
-        // registers -> LDS (rows past L were zero-filled: 0 * 0 terms are exact no-ops)
+    constexpr int EH = (TILES > 8) ? 8 : TILES;      // tiles per epilogue / prologue pass
+    constexpr int ENS = 16 * EH;                     // columns per pass
+    constexpr int LDT = ENS + 4;                     // pitch: rows 4 apart land 16 banks apart
+    constexpr int ELPR = ENS / 4;                    // lanes per row on the global side
+    constexpr int ERPI = 64 / ELPR;                  // rows per global instruction
+    static_assert(16 * LDT <= KT * SLD, "epilogue tile must fit the staging slice");
+
+    for (int rep = 0; rep < nrep; ++rep) {
+        int np, sg[G], sk0[G], slen[G], sfl[G];
+        if (together) {
+            np = m;
+#pragma unroll
+            for (int j = 0; j < G; ++j) { sg[j] = pg[j]; sk0[j] = pk0[j]; slen[j] = plen[j]; sfl[j] = pfl[j]; }
+        } else {
+            np = 1;
+            bool ok = inr[0];
+            sg[0] = pg[0]; sk0[0] = pk0[0]; slen[0] = plen[0]; sfl[0] = pfl[0];
+#pragma unroll
+            for (int j = 1; j < G; ++j) {
+                if (rep == j) { ok = inr[j]; sg[0] = pg[j]; sk0[0] = pk0[j]; slen[0] = plen[j]; sfl[0] = pfl[j]; }
+                sg[j] = sk0[j] = slen[j] = sfl[j] = 0;
+            }
+            if (!ok) continue;
+        }
+        const int L = slen[0];                       // the longest piece: B rows c0 .. c0+L-1 (or the L listed columns)
+        int rowstart[G];                             // this lane's row of piece j: first value of the piece
+#pragma unroll
+        for (int j = 0; j < G; ++j) rowstart[j] = (j < np) ? a.row_ptr[(sg[j] << 4) + i16] + sk0[j] : 0;
+        const int list0 = __builtin_amdgcn_readfirstlane(a.row_ptr[sg[0] << 4]) + sk0[0];   // list mode: where the piece's columns are stored
+
+        float4a acc[G][TILES];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[j][t] = (float4a){0.f, 0.f, 0.f, 0.f};
+        // pieces after a group's first continue the chain pass p-1 left in C
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (j < np && (sfl[j] & kPieceCarryIn)) {
+                const int r0 = sg[j] << 4;
+#pragma unroll
+                for (int h = 0; h < TILES / EH; ++h) {
+                    wave_lds_sync();
+#pragma unroll
+                    for (int it = 0; it < 16 / ERPI; ++it) {
+                        const int row = it * ERPI + lane / ELPR;
+                        const int c4 = 4 * (lane % ELPR);
+                        float4v v = (float4v){0.f, 0.f, 0.f, 0.f};
+                        if (r0 + row >= a.row_lo && r0 + row < a.row_hi)
+                            v = *reinterpret_cast<const float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4);
+                        *reinterpret_cast<float4v *>(lds + row * LDT + c4) = v;
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int t = 0; t < EH; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[j][h * EH + t][q] = lds[(4 * kq + q) * LDT + 16 * t + i16];
+                }
+            }
+        }
+
+        float4v R[LOADS];
+        float af[G][KS];
+        // A values of batch kb: lane (i16, kq) holds A[row i16][k = kb + 4s + kq] of every piece
+        auto fetch_a = [&](int kb) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int k = kb + 4 * s + kq;
+                    af[j][s] = (j < np && k < slen[j]) ? a.vals[rowstart[j] + k] : 0.f;
+                }
+        };
+        // run mode, whole batch inside the run: 8 unconditional loads of rows c0 + kb + ..
+        auto prefetch_run_full = [&](int kb) {
+#pragma unroll
+            for (int u = 0; u < LOADS; ++u)
+                R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + u * RPI + q_in));
+            fetch_a(kb);
+        };
+        // list mode: column indices run one batch ahead of the B rows they address (cj_next holds batch kb's
+        // indices when prefetch(kb) is called), so a prefetch is one memory round trip, not two dependent ones
+        int cj_next = (c0 < 0 && lane < KT && lane < L) ? a.col_idx[list0 + lane] : 0;
+        auto prefetch = [&](int kb) {
+            const int cj = cj_next;
+            if (c0 < 0) {
+                const int kk = kb + KT + lane;
+                cj_next = (lane < KT && kk < L) ? a.col_idx[list0 + kk] : 0;
+#pragma unroll
+                for (int u = 0; u < LOADS; ++u) {
+                    const int j = u * RPI + q_in;
+                    const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
+                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
+                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < LOADS; ++u) {
+                    const int j = u * RPI + q_in;
+                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
+                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + j));
+                }
+            }
+            fetch_a(kb);
+        };
+        auto prefetch_any = [&](int kb) {
+            if (c0 >= 0 && kb + KT <= L) prefetch_run_full(kb);
+            else prefetch(kb);
+        };
+
         wave_lds_sync();
+        prefetch_any(0);
+        for (int kb = 0; kb < L; kb += KT) {
+            // registers -> LDS (rows past L were zero-filled: 0 * 0 terms are exact no-ops)
+            wave_lds_sync();
 #pragma unroll
-        for (int u = 0; u < LOADS; ++u) {
-            const int j = u * RPI + q_in;
-            *reinterpret_cast<float4v *>(lds + j * SLD + 4 * (lane % LPRB)) = R[u];
+            for (int u = 0; u < LOADS; ++u) {
+                const int j = u * RPI + q_in;
+                *reinterpret_cast<float4v *>(lds + j * SLD + 4 * (lane % LPRB)) = R[u];
+            }
+            float acur[G][KS];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acur[j][s] = af[j][s];
+            wave_lds_sync();
+            if (kb + KT < L) prefetch_any(kb + KT);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k = kb + 4 * s;
+                if (G == 1 || np == 1 || k >= slen[G > 1 ? 1 : 0]) {
+                    // only the longest piece is active in this step (k < L may be false in the last batch: zero rows, zero values)
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
+                        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][s], b, acc[0][t], 0, 0, 0);
+                    }
+                } else {
+                    int nact = 2;
+#pragma unroll
+                    for (int j = 2; j < G; ++j) nact += (j < np && k < slen[j]) ? 1 : 0;
+                    if (G == 2 || nact == 2) {
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
+                            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][s], b, acc[0][t], 0, 0, 0);
+                            acc[G > 1 ? 1 : 0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[G > 1 ? 1 : 0][s], b, acc[G > 1 ? 1 : 0][t], 0, 0, 0);
+                        }
+                    } else if (G == 3 || nact == 3) {
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
+#pragma unroll
+                            for (int j = 0; j < (G < 3 ? G : 3); ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j][s], b, acc[j][t], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
+#pragma unroll
+                            for (int j = 0; j < G; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j][s], b, acc[j][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
         }
-        float acur[KS];
+        // Epilogue.  D reg q of lane l is C[r0 + 4*kq + q][slab0 + 16t + i16]: stored directly that is 4-byte
+        // elements in 64-byte runs (64 store instructions per lane, 30 % write amplification).  Instead each
+        // tile goes through the wave's LDS slice, at most 128 columns at a time, and leaves as whole
+        // 16-byte-per-lane row segments.  A tile that a later pass continues stays cacheable; a final one is nt.
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acur[s] = af[s];
-        wave_lds_sync();
-        if (kb + KT < L) prefetch(kb + KT);
+        for (int j = 0; j < G; ++j) {
+            if (j < np) {
+                const int r0 = sg[j] << 4;
+                const bool carried = (sfl[j] & kPieceCarryOut) != 0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+                for (int h = 0; h < TILES / EH; ++h) {
+                    wave_lds_sync();
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s], b, acc[t], 0, 0, 0);
+                    for (int t = 0; t < EH; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) lds[(4 * kq + q) * LDT + 16 * t + i16] = acc[j][h * EH + t][q];
+                    wave_lds_sync();
+#pragma unroll
+                    for (int it = 0; it < 16 / ERPI; ++it) {
+                        const int row = it * ERPI + lane / ELPR;
+                        const int c4 = 4 * (lane % ELPR);
+                        const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
+                        if (r0 + row >= a.row_lo && r0 + row < a.row_hi) {
+                            float4v *dst = reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4);
+                            if (carried) *dst = v;
+                            else __builtin_nontemporal_store(v, dst);
+                        }
+                    }
+                }
             }
         }
     }
-    // Epilogue.  D reg q of lane l is C[r0 + 4*kq + q][slab0 + 16t + i16]: stored directly that is 4-byte
-    // elements in 64-byte runs (64 store instructions per lane, 30 % write amplification, 16 % of the
-    // kernel).  Instead the tile goes through the wave's LDS slice, at most 128 columns at a time, and
-    // leaves as whole 16-byte-per-lane row segments.
-    constexpr int EH = (TILES > 8) ? 8 : TILES;      // tiles per epilogue pass
-    constexpr int ENS = 16 * EH;                     // columns per pass
-    constexpr int LDT = ENS + 4;                     // pitch: rows 4 apart land 16 banks apart
-    constexpr int ELPR = ENS / 4;                    // lanes per row when reading back
-    constexpr int ERPI = 64 / ELPR;                  // rows per store instruction
-    static_assert(16 * LDT <= KT * SLD, "epilogue tile must fit the staging slice");
+}
+
+// Cuts a qualifying group's column list (the list of its first row) into runs of consecutive columns.
+// One wave per group.  out[gi]: n = number of pieces (1..kMaxPieces); piece r covers positions
+// [k0[r], k0[r] + len[r]) of the list and is the column run c0[r], c0[r]+1, ... when c0[r] >= 0;
+// c0[r] = -1 - first_column marks a piece that is just a column list (no run structure).
+// A list with more than max_pieces runs, or with a run shorter than run_min, stays ONE list piece.
+__global__ __launch_bounds__(kBlockThreads) void analyze_group_runs(const int32_t *__restrict__ row_ptr,
+                                                                   const int32_t *__restrict__ col_idx,
+                                                                   const int32_t *__restrict__ groups, int32_t n_groups,
+                                                                   int32_t max_pieces, int32_t run_min,
+                                                                   GroupPieces *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int gi = (int)((blockIdx.x * (unsigned)kBlockThreads + threadIdx.x) >> 6);
+    if (gi >= n_groups) return;
+    const int r0 = groups[gi] << 4;
+    const int p0 = row_ptr[r0];
+    const int L = row_ptr[r0 + 1] - p0;
+    int nb = 0;                 // breaks found (wave-uniform)
+    int bpos[kMaxPieces - 1];   // positions where a new run starts
 #pragma unroll
-    for (int h = 0; h < TILES / EH; ++h) {
-        wave_lds_sync();
+    for (int i = 0; i < kMaxPieces - 1; ++i) bpos[i] = 0;
+    for (int base = 1; base < L; base += 64) {
+        const int k = base + lane;
+        const bool brk = (k < L) && (col_idx[p0 + k] != col_idx[p0 + k - 1] + 1);
+        unsigned long long mask = __ballot(brk);
+        while (mask) {
+            const int bit = __builtin_ctzll(mask);
+            mask &= mask - 1;
 #pragma unroll
-        for (int t = 0; t < EH; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lds[(4 * kq + q) * LDT + 16 * t + i16] = acc[h * EH + t][q];
-        wave_lds_sync();
-#pragma unroll
-        for (int it = 0; it < 16 / ERPI; ++it) {
-            const int row = it * ERPI + lane / ELPR;
-            const int c4 = 4 * (lane % ELPR);
-            const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
-            if (r0 + row >= a.row_lo && r0 + row < a.row_hi)
-                __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4));
+            for (int i = 0; i < kMaxPieces - 1; ++i)
+                if (nb == i) bpos[i] = base + bit;
+            ++nb;
         }
+        if (nb >= max_pieces) break;   // too many runs: a plain list
     }
+    if (lane != 0) return;
+    GroupPieces o;
+    const int first_col = col_idx[p0];
+    bool runs_ok = nb < max_pieces && nb < kMaxPieces;
+    int start[kMaxPieces + 1];
+    start[0] = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPieces - 1; ++i) start[i + 1] = (i < nb) ? bpos[i] : L;
+    start[kMaxPieces] = L;
+    if (runs_ok) {
+#pragma unroll
+        for (int i = 0; i < kMaxPieces; ++i)
+            if (i <= nb && start[i + 1] - start[i] < run_min) runs_ok = false;
+    }
+    // a single run is always a run piece (no carry involved), whatever its length
+    if (nb == 0) runs_ok = true;
+    if (runs_ok) {
+        o.n = nb + 1;
+#pragma unroll
+        for (int i = 0; i < kMaxPieces; ++i) {
+            const bool used = i <= nb;
+            o.k0[i] = used ? start[i] : 0;
+            o.len[i] = used ? start[i + 1] - start[i] : 0;
+            o.c0[i] = used ? col_idx[p0 + start[i]] : 0;
+        }
+    } else {
+        o.n = 1;
+#pragma unroll
+        for (int i = 0; i < kMaxPieces; ++i) { o.k0[i] = 0; o.len[i] = 0; o.c0[i] = 0; }
+        o.len[0] = L;
+        o.c0[0] = -1 - first_col;
+    }
+    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    out[gi] = o;
 }
 
 // ---- CSR sanity: column range (an out-of-range column would fault the GPU) ----

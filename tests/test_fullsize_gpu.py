@@ -124,7 +124,7 @@ def test_c2_power_law_full_size(device, oracle):
 
     ptr, idx, vals, B, meta = synth.config("C2")
     M, N = meta["M"], meta["N"]
-    assert M == 1 << 20 and meta["deg_max"] == 4096
+    assert M == 1 << 20 and 4000 <= meta["deg_max"] <= 4096      # duplicate (row, col) draws are dropped
     (d_B,) = to_dev(device, B)
     d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, M)
     thr = op.get_option("long_row_threshold")

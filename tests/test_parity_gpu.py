@@ -383,6 +383,116 @@ def test_product_library_refuses_ablation_options(device):
     op.set_option("kernel", 2)
 
 
+def _run_groups_case(n_groups, K, N, seed, lens=(32, 36, 40, 64, 96, 128, 33, 200), slots=12, tail_rows=3):
+    """16-row groups whose shared column list is 1-3 RUNS of consecutive columns drawn from a small pool of start
+    columns (so that runs of different groups coincide and get shared), next to groups with a too-short run, groups
+    with a plain random list and ragged rows.  Returns (ptr, idx, vals, B, expected number of pieces per group kind)."""
+    g = np.random.Generator(np.random.Philox(key=[seed, 0]))
+    pitch = K // slots                      # one possible run start per slot; a run never reaches the next slot's start
+    assert pitch > max(lens) + 2
+    ptr, idx, n_runs_of = [0], [], []
+    for b in range(n_groups):
+        kind = int(g.integers(0, 6))        # 0-3: run groups, 4: random list, 5: ragged rows
+        if kind <= 3:
+            nr = int(g.integers(1, 4))
+            sl = np.sort(g.choice(slots, nr, replace=False))
+            cols = []
+            for q in sl:
+                L = int(g.choice(lens)) if kind != 3 else int(g.choice([5, 64, 12]))   # kind 3: may hold a run < 32
+                cols.append(np.arange(q * pitch, q * pitch + L))
+            cols = np.concatenate(cols).astype(np.int32)
+            n_runs_of.append(nr)
+            for _ in range(16):
+                idx.append(cols)
+                ptr.append(ptr[-1] + cols.size)
+        elif kind == 4:
+            cols = g.integers(0, K, size=int(g.integers(8, 150))).astype(np.int32)
+            for _ in range(16):
+                idx.append(cols)
+                ptr.append(ptr[-1] + cols.size)
+        else:
+            for _ in range(16):
+                d = int(g.integers(0, 40))
+                idx.append(np.sort(g.choice(K, d, replace=False)).astype(np.int32))
+                ptr.append(ptr[-1] + d)
+    for _ in range(tail_rows):
+        d = int(g.integers(1, 30))
+        idx.append(np.sort(g.choice(K, d, replace=False)).astype(np.int32))
+        ptr.append(ptr[-1] + d)
+    ptr = np.asarray(ptr, np.int32)
+    idx = np.concatenate(idx).astype(np.int32)
+    return ptr, idx, synth.normal_f32(idx.size, seed + 1), synth.normal_f32(K * N, seed + 2).reshape(K, N)
+
+
+@pytest.mark.parametrize("N", [32, 64, 128, 256, 384, 512])
+def test_block_path_shared_runs_and_passes(device, oracle, N):
+    """The block path's items: runs shared by several groups (one staged B tile feeding two groups' MFMAs), lists cut
+    into up to three runs = up to three passes whose fma chains continue through C, runs whose length is not a
+    multiple of the MFMA k-step (never shared), lists with a short run (kept whole).  Always the oracle's bits, and
+    the same bits with sharing / cutting switched off."""
+    ptr, idx, vals, B = _run_groups_case(160, 3000, N, seed=7100 + N)
+    ref = oracle.spmm_omp(ptr, idx, vals, B)
+    C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 2048})
+    assert op.get_option("n_block_groups") > 80
+    assert op.get_option("n_block_passes") == 3
+    assert op.get_option("n_block_pieces") > op.get_option("n_block_groups")
+    if N % 128 == 0:
+        assert op.get_option("n_block_shared_items") > 20
+    else:
+        assert op.get_option("n_block_shared_items") == 0        # the two-piece kernels exist for 128/256-column slabs
+    assert not np.isnan(C).any()
+    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).any(axis=1).sum()} rows differ"
+    for opts in ({"block_share": 1}, {"block_max_pieces": 1}, {"block_max_pieces": 2, "block_run_min": 64}, {"block_path": 0}):
+        o = {"long_row_threshold": 2048}
+        o.update(opts)
+        C2, op2 = run_spmm(device, ptr, idx, vals, B, options=o)
+        assert np.array_equal(bits(C2), bits(ref)), opts
+        if "block_share" in opts:
+            assert op2.get_option("n_block_shared_items") == 0
+        if opts.get("block_max_pieces") == 1:
+            assert op2.get_option("n_block_passes") == 1 and op2.get_option("n_block_pieces") == op2.get_option("n_block_groups")
+
+
+def test_block_items_row_panels_pitches_and_special_values(device, oracle):
+    """Shared items whose pieces fall on different sides of a row-range boundary (the multi-GPU driver's row panels),
+    C with a row pitch wider than N, and inf / NaN / -0 / subnormals in A and B: a shorter piece of a shared item
+    must not multiply the longer piece's extra B rows (0 * inf would poison it), carried tiles must round-trip
+    exactly."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    g = np.random.Generator(np.random.Philox(key=[77, 9]))
+    ptr, idx, vals, B = _run_groups_case(120, 2600, 256, seed=4321)
+    special = np.array([np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-40, -3e-42, 1.1754942e-38, 3.4e38, -3.4e38], np.float32)
+    vals[g.integers(0, vals.size, 600)] = special[g.integers(0, special.size, 600)]
+    B.reshape(-1)[g.integers(0, B.size, 6000)] = special[g.integers(0, special.size, 6000)]
+    ref = oracle.spmm_omp(ptr, idx, vals, B)
+    assert np.isnan(ref).any() and np.isinf(ref).any()
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), 256, num_cols=2600)
+    op.set_option("long_row_threshold", 2048)
+    wide = torch.full((M, 512), float("nan"), dtype=torch.float32, device=device)
+    op.preprocess(d_B, wide)
+    assert op.get_option("n_block_shared_items") > 10 and op.get_option("n_block_passes") == 3
+    cuts = [0, 16, 200, 203, 640, 1111, M]
+    for r0, r1 in zip(cuts, cuts[1:]):
+        op.run_rows(d_B, 256, wide.view(-1)[256:], 512, r0, r1)       # right half of a wider C, ragged row ranges
+    torch.cuda.synchronize()
+    got = wide[:, 256:].cpu().numpy()
+    same = (bits(got) == bits(ref)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), int((~same).sum())
+    assert torch.isnan(wide[:, :256]).all()
+    # exactly the requested rows are written, also when the range cuts a group and an item
+    C = torch.full((M, 256), float("nan"), dtype=torch.float32, device=device)
+    op.run_rows(d_B, 256, C, 256, 37, 999)
+    torch.cuda.synchronize()
+    got = C.cpu().numpy()
+    same = (bits(got[37:999]) == bits(ref[37:999])) | (np.isnan(got[37:999]) & np.isnan(ref[37:999]))
+    assert same.all()
+    assert np.isnan(got[:37]).all() and np.isnan(got[999:]).all()
+
+
 @pytest.mark.parametrize("N", [32, 128, 36])
 def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N):
     """mi_spmm_run_rows on an arbitrary range: exactly those rows of C are written -- short rows, medium rows
