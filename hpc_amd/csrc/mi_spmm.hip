@@ -66,16 +66,14 @@ struct mi_spmm_handle {
     int64_t block_max_pieces;  // most pieces a group's list is cut into = most passes (1 = never cut)
     int64_t block_run_min;     // shortest run worth a piece of its own
     BlockItem *d_blk_items;
-    BlockPiece *d_blk_pieces;
     int32_t n_blk_items, n_blk_pieces, n_blk_passes, n_blk_shared_items;
-    struct { int32_t off, n; } blk_launch[kMaxPieces][2];   // [pass][0: single-piece items, 1: shared items]
+    struct { int32_t off, n; } blk_launch[kMaxPieces][3];   // [pass][0: list items, 1: run items of one piece, 2: shared run items]
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
 // Pieces of a split row: the plan builders step through a row in int32; a piece length far beyond any row
 // that can be split usefully would overflow `b + clen`.
 static const int64_t kMaxLongChunk = 1 << 20;
-static const int kMaxShare = 2;   // widest item the block kernels are instantiated for (spmm_block_items<.., G, ..>)
 
 static bool good(const mi_spmm_handle *h) { return h && h->magic == kMagic; }
 
@@ -87,9 +85,7 @@ static void free_plan(mi_spmm_handle *h)
     if (h->d_blk_flag) (void)hipFree(h->d_blk_flag);
     if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
     if (h->d_blk_items) (void)hipFree(h->d_blk_items);
-    if (h->d_blk_pieces) (void)hipFree(h->d_blk_pieces);
     h->d_blk_items = nullptr;
-    h->d_blk_pieces = nullptr;
     h->n_blk_items = h->n_blk_pieces = h->n_blk_passes = h->n_blk_shared_items = 0;
     std::memset(h->blk_launch, 0, sizeof(h->blk_launch));
     h->d_blk_flag = nullptr;
@@ -112,7 +108,7 @@ static bool block_path_shape_ok(int32_t N) { return block_slab_width(N) != 0; }
 // pieces on the device (analyze_group_runs: one wave per group, O(nnz / 16) reads); the pieces -- a few per
 // group -- come back to the host, which orders every pass's pieces by first column and forms the items:
 // run pieces with the same first column share their B rows (longest first, at most block_share per item, every
-// shared length a multiple of the MFMA k-step so that no piece ends inside a step).  O(groups log groups) on
+// shared length a whole number of k batches so that no shared piece ends inside a batch).  O(groups log groups) on
 // the host, once per preprocess; untimed by the reference's harness (test_spmm.cu:58).
 static int build_block_items(mi_spmm_handle *h)
 {
@@ -132,12 +128,26 @@ static int build_block_items(mi_spmm_handle *h)
 
     struct Key { int32_t col, len, gi, ord; bool shareable; };
     std::vector<BlockItem> items;
-    std::vector<BlockPiece> pieces;
+    int64_t n_pieces = 0;
+    std::vector<int32_t> ptr16((size_t)ng), len16((size_t)ng);   // row_ptr[16 g] and the common row length of every qualifying group
+    {
+        // two strided gathers from the device row_ptr: positions 16 g and 16 g + 1
+        std::vector<int32_t> pos((size_t)ng);
+        for (int32_t gi = 0; gi < ng; ++gi) pos[(size_t)gi] = groups[(size_t)gi] * 16;
+        // (one row_ptr copy is simpler than a gather kernel and is O(M) bytes once per preprocess)
+        std::vector<int32_t> ptr((size_t)h->num_v + 1);
+        e = hipMemcpy(ptr.data(), h->d_ptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return (int)e;
+        for (int32_t gi = 0; gi < ng; ++gi) {
+            ptr16[(size_t)gi] = ptr[(size_t)pos[(size_t)gi]];
+            len16[(size_t)gi] = ptr[(size_t)pos[(size_t)gi] + 1] - ptr[(size_t)pos[(size_t)gi]];
+        }
+    }
     int32_t n_pass = 0, n_shared = 0;
     // shared items need the two-piece kernels, which exist for 256- and 128-column slabs (N % 128 == 0)
     const int share = block_slab_width(h->feat) >= 128 ? (int)h->block_share : 1;
     std::vector<Key> keys;
-    std::vector<BlockItem> singles, shared;
+    std::vector<BlockItem> lists, singles, shared;
     for (int pass = 0; pass < kMaxPieces; ++pass) {
         keys.clear();
         for (int32_t gi = 0; gi < ng; ++gi) {
@@ -149,7 +159,7 @@ static int build_block_items(mi_spmm_handle *h)
             k.len = g.len[pass];
             k.gi = gi;
             k.ord = pass;
-            k.shareable = c >= 0 && (g.len[pass] % 4) == 0 && share > 1;
+            k.shareable = c >= 0 && (g.len[pass] % kShareLenUnit) == 0 && share > 1;
             keys.push_back(k);
         }
         if (keys.empty()) break;
@@ -161,6 +171,7 @@ static int build_block_items(mi_spmm_handle *h)
             if (a.len != b.len) return a.len > b.len;
             return a.gi < b.gi;
         });
+        lists.clear();
         singles.clear();
         shared.clear();
         size_t i = 0;
@@ -169,43 +180,41 @@ static int build_block_items(mi_spmm_handle *h)
             if (keys[i].shareable)
                 while (j < keys.size() && j - i < (size_t)share && keys[j].shareable && keys[j].col == keys[i].col) ++j;
             BlockItem it;
-            it.first = (int32_t)pieces.size();
+            std::memset(&it, 0, sizeof(it));
             it.m = (int32_t)(j - i);
             const GroupPieces &g0 = gp[(size_t)keys[i].gi];
             it.c0 = g0.c0[pass];
-            it.len_max = keys[i].len;
             for (size_t q = i; q < j; ++q) {
                 const GroupPieces &g = gp[(size_t)keys[q].gi];
-                BlockPiece p;
+                BlockPiece &p = it.p[q - i];
                 p.group = groups[(size_t)keys[q].gi];
                 p.k0 = g.k0[pass];
                 p.len = g.len[pass];
                 p.flags = (pass > 0 ? kPieceCarryIn : 0) | (pass + 1 < g.n ? kPieceCarryOut : 0);
-                pieces.push_back(p);
+                p.p0 = ptr16[(size_t)keys[q].gi];
+                p.row_len = len16[(size_t)keys[q].gi];
+                ++n_pieces;
             }
-            (it.m > 1 ? shared : singles).push_back(it);
+            (it.c0 < 0 ? lists : it.m > 1 ? shared : singles).push_back(it);
             i = j;
         }
-        h->blk_launch[pass][0].off = (int32_t)items.size();
-        h->blk_launch[pass][0].n = (int32_t)singles.size();
-        items.insert(items.end(), singles.begin(), singles.end());
-        h->blk_launch[pass][1].off = (int32_t)items.size();
-        h->blk_launch[pass][1].n = (int32_t)shared.size();
-        items.insert(items.end(), shared.begin(), shared.end());
+        std::vector<BlockItem> *cls[3] = {&lists, &singles, &shared};
+        for (int c = 0; c < 3; ++c) {
+            h->blk_launch[pass][c].off = (int32_t)items.size();
+            h->blk_launch[pass][c].n = (int32_t)cls[c]->size();
+            items.insert(items.end(), cls[c]->begin(), cls[c]->end());
+        }
         n_shared += (int32_t)shared.size();
     }
     if (items.empty()) return MI_SPMM_OK;
-    if (hipMalloc((void **)&h->d_blk_items, items.size() * sizeof(BlockItem)) != hipSuccess ||
-        hipMalloc((void **)&h->d_blk_pieces, pieces.size() * sizeof(BlockPiece)) != hipSuccess)
-        return MI_SPMM_ENOMEM;
+    if (hipMalloc((void **)&h->d_blk_items, items.size() * sizeof(BlockItem)) != hipSuccess) return MI_SPMM_ENOMEM;
     e = hipMemcpy(h->d_blk_items, items.data(), items.size() * sizeof(BlockItem), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(h->d_blk_pieces, pieces.data(), pieces.size() * sizeof(BlockPiece), hipMemcpyHostToDevice);
     if (e != hipSuccess) return (int)e;
     h->n_blk_items = (int32_t)items.size();
-    h->n_blk_pieces = (int32_t)pieces.size();
+    h->n_blk_pieces = (int32_t)n_pieces;
     h->n_blk_passes = n_pass;
     h->n_blk_shared_items = n_shared;
-    h->ws_bytes += items.size() * sizeof(BlockItem) + pieces.size() * sizeof(BlockPiece);
+    h->ws_bytes += items.size() * sizeof(BlockItem);
     return MI_SPMM_OK;
 }
 
@@ -729,19 +738,21 @@ void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s, in
     }
 }
 
-template <int G, bool WIDE>
+template <int G, bool WIDE, bool RUN>
 void launch_block_items_g(int slab, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
     // shared items (G > 1) exist only for slabs of 256 or 128 columns (N % 128 == 0); narrower N runs every item alone
-    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<16, G, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<8, G, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<4, 1, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<2, 1, WIDE>), grid, dim3(kBlockThreads), 0, s, a);
+    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<16, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<8, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<4, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<2, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
 }
-void launch_block_items(int slab, int g, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
+// cls: 0 = list items, 1 = run items holding one piece, 2 = run items sharing their B rows between two pieces
+void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
-    if (g > 1) { if (wide) launch_block_items_g<2, true>(slab, a, grid, s); else launch_block_items_g<2, false>(slab, a, grid, s); }
-    else { if (wide) launch_block_items_g<1, true>(slab, a, grid, s); else launch_block_items_g<1, false>(slab, a, grid, s); }
+    if (cls == 2) { if (wide) launch_block_items_g<2, true, true>(slab, a, grid, s); else launch_block_items_g<2, false, true>(slab, a, grid, s); }
+    else if (cls == 1) { if (wide) launch_block_items_g<1, true, true>(slab, a, grid, s); else launch_block_items_g<1, false, true>(slab, a, grid, s); }
+    else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s); else launch_block_items_g<1, false, false>(slab, a, grid, s); }
 }
 
 // auto: see profiles/r02_wide_n_tiles.txt
@@ -845,7 +856,6 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
                              ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
     if (blocks_on && launch_blocks_here) {
         BlockArgs ba;
-        ba.pieces = h->d_blk_pieces;
         ba.row_ptr = h->d_ptr;
         ba.col_idx = h->d_idx;
         ba.vals = h->d_val;
@@ -860,13 +870,13 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         const int slab = block_slab_width(full.N), slabs = full.N / slab;
         // pass p continues the fma chains pass p-1 left in C: stream order is the dependency
         for (int pass = 0; pass < h->n_blk_passes; ++pass) {
-            for (int cls = 1; cls >= 0; --cls) {
+            for (int cls = 2; cls >= 0; --cls) {
                 const int32_t n = h->blk_launch[pass][cls].n;
                 if (n == 0) continue;
                 ba.items = h->d_blk_items + h->blk_launch[pass][cls].off;
                 ba.n_items = n;
                 dim3 bgrid((unsigned)((n + 3) / 4), slabs);
-                launch_block_items(slab, cls ? 2 : 1, wide_full, ba, bgrid, s);
+                launch_block_items(slab, cls, wide_full, ba, bgrid, s);
                 ++launches;
             }
         }

@@ -1,0 +1,438 @@
+// mi_spmm_dist.cpp -- the column-sharded multi-GPU step behind a C ABI (include/mi_spmm_dist.h).
+//
+// Host code only: streams, events, RCCL calls, strided peer copies.  The kernels are libmi_spmm.so's
+// (mi_spmm_run_rows, mi_spmm_unpack_gathered).  One process per GPU; the reference has no counterpart
+// (PA4/workspace/include/util.h:30 is a commented-out `extern ncclComm_t comm;`).
+//
+//   compute stream (the caller's) :  rows(p0) | rows(p1) | rows(p2) | ...
+//   exchange stream(s)            :           | gather(p0) | gather(p1) | ...          (back to back: link-bound)
+//   re-layout stream              :                        | unpack(p0) | unpack(p1) | ...     (not in peer2d mode)
+#include "../../include/mi_spmm_dist.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+enum { kAllGather = 0, kDirect = 1, kPeer2D = 2 };
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define NCCL_TRY(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return MI_SPMM_DIST_ENCCL_BASE - (int)r_; } while (0)
+#define MI_TRY(x) do { int c_ = (x); if (c_ != 0) return c_; } while (0)
+
+}  // namespace
+
+struct mi_spmm_dist {
+    uint32_t magic = 0x4d494453u;  // "MIDS"
+    mi_spmm_handle *h = nullptr;
+    int32_t M = 0, n_loc = 0, rank = 0, world = 1, n_panels = 1;
+    int64_t N_total = 0;
+    int exchange = kAllGather;
+    std::vector<std::pair<int32_t, int32_t>> panels;
+    int32_t rows_max = 0;
+    // streams / events (created on first use, on the device current at that time)
+    bool streams_ready = false;
+    hipStream_t s_comm = nullptr, s_post = nullptr;
+    std::vector<hipStream_t> s_push;           // peer2d: one per peer, so every link runs at the same time
+    hipEvent_t ev_start = nullptr;
+    std::vector<hipEvent_t> ev_computed, ev_gathered;
+    hipEvent_t ev_unpacked[2] = {nullptr, nullptr};
+    bool unpacked_valid[2] = {false, false};
+    std::vector<hipEvent_t> ev_pushed;         // per peer stream
+    // staging (allgather / direct)
+    float *staging[2] = {nullptr, nullptr};
+    size_t staging_elems = 0;
+    // communicator
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    float *d_token = nullptr;                  // one float: the all-reduce that serves as a device-side barrier
+    // peers (peer2d)
+    std::vector<void *> peer_base;             // what hipIpcOpenMemHandle returned (to close)
+    std::vector<float *> peer_C;               // the peers' C_full
+    float *exported_C = nullptr;
+};
+
+namespace {
+
+bool good(const mi_spmm_dist *d) { return d && d->magic == 0x4d494453u; }
+
+void make_panels(mi_spmm_dist *d)
+{
+    d->panels.clear();
+    d->rows_max = 0;
+    if (d->M <= 0) return;
+    const int64_t np = d->n_panels < 1 ? 1 : d->n_panels;
+    int64_t per = (d->M + np - 1) / np;
+    per = (per + 255) / 256 * 256;
+    for (int64_t r = 0; r < d->M; r += per) {
+        const int64_t e = r + per < d->M ? r + per : d->M;
+        d->panels.emplace_back((int32_t)r, (int32_t)e);
+        if (e - r > d->rows_max) d->rows_max = (int32_t)(e - r);
+    }
+}
+
+void free_staging(mi_spmm_dist *d)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (d->staging[i]) (void)hipFree(d->staging[i]);
+        d->staging[i] = nullptr;
+    }
+    d->staging_elems = 0;
+}
+
+int ensure_streams(mi_spmm_dist *d)
+{
+    if (d->streams_ready) return 0;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = highest priority
+    // exchange and re-layout at high priority: they must not queue behind a compute kernel that fills every CU
+    HIP_TRY(hipStreamCreateWithPriority(&d->s_comm, hipStreamNonBlocking, hi));
+    HIP_TRY(hipStreamCreateWithPriority(&d->s_post, hipStreamNonBlocking, hi));
+    HIP_TRY(hipEventCreateWithFlags(&d->ev_start, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&d->ev_unpacked[i], hipEventDisableTiming));
+    d->streams_ready = true;
+    return 0;
+}
+
+int ensure_panel_events(mi_spmm_dist *d)
+{
+    while (d->ev_computed.size() < d->panels.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        d->ev_computed.push_back(a);
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        d->ev_gathered.push_back(b);
+    }
+    return 0;
+}
+
+int ensure_push_streams(mi_spmm_dist *d)
+{
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    while ((int)d->s_push.size() < d->world - 1) {
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+        d->s_push.push_back(s);
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->ev_pushed.push_back(e);
+    }
+    return 0;
+}
+
+int ensure_staging(mi_spmm_dist *d)
+{
+    const size_t need = (size_t)d->world * (size_t)d->rows_max * (size_t)d->n_loc;
+    if (d->staging[0] && d->staging_elems >= need) return 0;
+    free_staging(d);
+    for (int i = 0; i < 2; ++i)
+        if (hipMalloc((void **)&d->staging[i], (need ? need : 1) * sizeof(float)) != hipSuccess) { free_staging(d); return MI_SPMM_ENOMEM; }
+    d->staging_elems = need;
+    d->unpacked_valid[0] = d->unpacked_valid[1] = false;
+    return 0;
+}
+
+int ensure_token(mi_spmm_dist *d)
+{
+    if (d->d_token) return 0;
+    HIP_TRY(hipMalloc((void **)&d->d_token, 256));
+    HIP_TRY(hipMemset(d->d_token, 0, 256));
+    return 0;
+}
+
+// every rank has finished everything it enqueued on its exchange stream before this point
+int device_barrier(mi_spmm_dist *d, hipStream_t s)
+{
+    if (!d->comm || d->world == 1) return 0;
+    MI_TRY(ensure_token(d));
+    NCCL_TRY(ncclAllReduce(d->d_token, d->d_token, 1, ncclFloat, ncclSum, d->comm, s));
+    return 0;
+}
+
+void close_peers(mi_spmm_dist *d)
+{
+    for (void *b : d->peer_base)
+        if (b) (void)hipIpcCloseMemHandle(b);
+    d->peer_base.clear();
+    d->peer_C.clear();
+}
+
+// fill stage[world][rows][n_loc] with every rank's block; the rank's own block already sits in its slot
+int exchange_panel(mi_spmm_dist *d, float *stage, int32_t rows, hipStream_t s)
+{
+    const size_t blk = (size_t)rows * (size_t)d->n_loc;
+    float *own = stage + (size_t)d->rank * blk;
+    if (d->world == 1) return 0;
+    if (d->exchange == kAllGather) {
+        NCCL_TRY(ncclAllGather(own, stage, blk, ncclFloat, d->comm, s));   // in place: sendbuff == recvbuff + rank * count
+        return 0;
+    }
+    // all-pairs: rank r sends to r+k while it receives from r-k, every k a perfect matching
+    NCCL_TRY(ncclGroupStart());
+    for (int k = 1; k < d->world; ++k) {
+        const int to = (d->rank + k) % d->world, from = (d->rank - k + d->world) % d->world;
+        ncclResult_t r = ncclSend(own, blk, ncclFloat, to, d->comm, s);
+        if (r == ncclSuccess) r = ncclRecv(stage + (size_t)from * blk, blk, ncclFloat, from, d->comm, s);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return MI_SPMM_DIST_ENCCL_BASE - (int)r; }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+}
+
+int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t main, bool do_compute, bool do_exchange)
+{
+    if (!good(d)) return MI_SPMM_ESTATE;
+    if (d->M == 0 || d->n_loc == 0) return 0;
+    if (!d_C_full || (do_compute && !d_B_loc)) return MI_SPMM_EINVAL;
+    const int64_t n_loc = d->n_loc, NT = d->N_total;
+    if (d->world == 1) {   // nothing to exchange: the local block IS C
+        if (do_compute) return mi_spmm_run_rows(d->h, d_B_loc, n_loc, d_C_full, NT, 0, d->M, (void *)main);
+        return 0;
+    }
+    if (d->exchange == kPeer2D) {
+        if ((int)d->peer_C.size() != d->world || d->exported_C != d_C_full) return MI_SPMM_ESTATE;
+    } else if (!d->comm) return MI_SPMM_ESTATE;
+    MI_TRY(ensure_streams(d));
+    MI_TRY(ensure_panel_events(d));
+    HIP_TRY(hipEventRecord(d->ev_start, main));
+    HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_start, 0));   // earlier work on the caller's stream (readers of C_full, staging)
+
+    if (d->exchange == kPeer2D) {
+        MI_TRY(ensure_push_streams(d));
+        // nobody may still be consuming the C_full we are about to overwrite remotely
+        if (do_exchange) MI_TRY(device_barrier(d, d->s_comm));
+        HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));     // reused as "step may start pushing"
+        for (hipStream_t s : d->s_push) HIP_TRY(hipStreamWaitEvent(s, d->ev_gathered[0], 0));
+        float *own = d_C_full + (size_t)d->rank * (size_t)n_loc;
+        for (size_t p = 0; p < d->panels.size(); ++p) {
+            const int32_t r0 = d->panels[p].first, r1 = d->panels[p].second;
+            if (do_compute) MI_TRY(mi_spmm_run_rows(d->h, d_B_loc, n_loc, own, NT, r0, r1, (void *)main));
+            HIP_TRY(hipEventRecord(d->ev_computed[p], main));
+            if (!do_exchange) continue;
+            int si = 0;
+            for (int k = 1; k < d->world; ++k, ++si) {
+                const int to = (d->rank + k) % d->world;
+                HIP_TRY(hipStreamWaitEvent(d->s_push[si], d->ev_computed[p], 0));
+                const size_t off = (size_t)r0 * (size_t)NT + (size_t)d->rank * (size_t)n_loc;
+                HIP_TRY(hipMemcpy2DAsync(d->peer_C[to] + off, (size_t)NT * 4, d_C_full + off, (size_t)NT * 4, (size_t)n_loc * 4,
+                                         (size_t)(r1 - r0), hipMemcpyDeviceToDevice, d->s_push[si]));
+            }
+        }
+        if (do_exchange) {
+            for (size_t i = 0; i < d->s_push.size(); ++i) {
+                HIP_TRY(hipEventRecord(d->ev_pushed[i], d->s_push[i]));
+                HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_pushed[i], 0));
+            }
+            MI_TRY(device_barrier(d, d->s_comm));                   // every rank's pushes have landed
+            HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));
+            HIP_TRY(hipStreamWaitEvent(main, d->ev_gathered[0], 0));
+        }
+        return 0;
+    }
+
+    MI_TRY(ensure_staging(d));
+    HIP_TRY(hipStreamWaitEvent(d->s_post, d->ev_start, 0));
+    for (size_t p = 0; p < d->panels.size(); ++p) {
+        const int32_t r0 = d->panels[p].first, r1 = d->panels[p].second, rows = r1 - r0;
+        float *stage = d->staging[p & 1];
+        float *own = stage + (size_t)d->rank * (size_t)rows * (size_t)n_loc;
+        // the staging buffer's previous contents (panel p-2, or the previous step) have been consumed
+        if (d->unpacked_valid[p & 1]) HIP_TRY(hipStreamWaitEvent(main, d->ev_unpacked[p & 1], 0));
+        // the rank's block goes straight into its slot of the staging buffer: the all-gather is in place
+        if (do_compute) MI_TRY(mi_spmm_run_rows(d->h, d_B_loc, n_loc, own - (size_t)r0 * (size_t)n_loc, n_loc, r0, r1, (void *)main));
+        HIP_TRY(hipEventRecord(d->ev_computed[p], main));
+        if (!do_exchange) continue;
+        HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_computed[p], 0));
+        MI_TRY(exchange_panel(d, stage, rows, d->s_comm));
+        HIP_TRY(hipEventRecord(d->ev_gathered[p], d->s_comm));
+        HIP_TRY(hipStreamWaitEvent(d->s_post, d->ev_gathered[p], 0));
+        MI_TRY(mi_spmm_unpack_gathered(stage, d_C_full + (size_t)r0 * (size_t)NT, rows, d->world, (int32_t)n_loc, NT, (void *)d->s_post));
+        HIP_TRY(hipEventRecord(d->ev_unpacked[p & 1], d->s_post));
+        d->unpacked_valid[p & 1] = true;
+    }
+    if (do_exchange) {
+        // the re-layout stream runs the panels in order: its last event covers the step
+        const size_t last = d->panels.size() - 1;
+        HIP_TRY(hipStreamWaitEvent(main, d->ev_unpacked[last & 1], 0));
+        if (d->panels.size() > 1) HIP_TRY(hipStreamWaitEvent(main, d->ev_unpacked[(last - 1) & 1], 0));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_spmm_dist_create(mi_spmm_dist **out, mi_spmm_handle *h, int32_t num_v, int32_t n_loc, int32_t rank, int32_t world,
+                        int32_t n_panels)
+{
+    if (!out) return MI_SPMM_EINVAL;
+    *out = nullptr;
+    if (!h || num_v < 0 || n_loc < 0 || world < 1 || rank < 0 || rank >= world || n_panels < 1) return MI_SPMM_EINVAL;
+    int64_t prepared = 0;
+    MI_TRY(mi_spmm_get_option(h, "prepared", &prepared));
+    if (!prepared) return MI_SPMM_ESTATE;
+    mi_spmm_dist *d = new (std::nothrow) mi_spmm_dist();
+    if (!d) return MI_SPMM_ENOMEM;
+    d->h = h;
+    d->M = num_v;
+    d->n_loc = n_loc;
+    d->rank = rank;
+    d->world = world;
+    d->n_panels = n_panels;
+    d->N_total = (int64_t)world * n_loc;
+    make_panels(d);
+    *out = d;
+    return 0;
+}
+
+int mi_spmm_dist_destroy(mi_spmm_dist *d)
+{
+    if (!d) return 0;
+    if (!good(d)) return MI_SPMM_ESTATE;
+    (void)hipDeviceSynchronize();
+    close_peers(d);
+    free_staging(d);
+    if (d->d_token) (void)hipFree(d->d_token);
+    if (d->comm && d->own_comm) (void)ncclCommDestroy(d->comm);
+    for (hipEvent_t e : d->ev_computed) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->ev_gathered) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->ev_pushed) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (d->ev_unpacked[i]) (void)hipEventDestroy(d->ev_unpacked[i]);
+    if (d->ev_start) (void)hipEventDestroy(d->ev_start);
+    for (hipStream_t s : d->s_push) (void)hipStreamDestroy(s);
+    if (d->s_comm) (void)hipStreamDestroy(d->s_comm);
+    if (d->s_post) (void)hipStreamDestroy(d->s_post);
+    d->magic = 0;
+    delete d;
+    return 0;
+}
+
+int mi_spmm_dist_unique_id(void *id_out)
+{
+    static_assert(sizeof(ncclUniqueId) == MI_SPMM_DIST_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return MI_SPMM_EINVAL;
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int mi_spmm_dist_comm_init(mi_spmm_dist *d, const void *id)
+{
+    if (!good(d) || !id) return MI_SPMM_EINVAL;
+    if (d->comm && d->own_comm) (void)ncclCommDestroy(d->comm);
+    d->comm = nullptr;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCL_TRY(ncclCommInitRank(&d->comm, d->world, uid, d->rank));
+    d->own_comm = true;
+    return 0;
+}
+
+int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm)
+{
+    if (!good(d)) return MI_SPMM_EINVAL;
+    if (d->comm && d->own_comm) (void)ncclCommDestroy(d->comm);
+    d->comm = (ncclComm_t)nccl_comm;
+    d->own_comm = false;
+    return 0;
+}
+
+int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == MI_SPMM_DIST_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    if (!good(d) || !d_C_full || !handle_out || !offset_out) return MI_SPMM_EINVAL;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d_C_full));   // the caller's allocator may sub-allocate
+    hipIpcMemHandle_t hnd;
+    HIP_TRY(hipIpcGetMemHandle(&hnd, base));
+    std::memcpy(handle_out, &hnd, sizeof(hnd));
+    *offset_out = (int64_t)((char *)d_C_full - (char *)base);
+    return 0;
+}
+
+int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets)
+{
+    if (!good(d) || !d_C_full || !handles || !offsets) return MI_SPMM_EINVAL;
+    close_peers(d);
+    d->peer_base.assign((size_t)d->world, nullptr);
+    d->peer_C.assign((size_t)d->world, nullptr);
+    for (int q = 0; q < d->world; ++q) {
+        if (q == d->rank) { d->peer_C[(size_t)q] = d_C_full; continue; }
+        hipIpcMemHandle_t hnd;
+        std::memcpy(&hnd, (const char *)handles + (size_t)q * sizeof(hnd), sizeof(hnd));
+        void *base = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&base, hnd, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { close_peers(d); return (int)e; }
+        d->peer_base[(size_t)q] = base;
+        d->peer_C[(size_t)q] = (float *)((char *)base + offsets[q]);
+    }
+    d->exported_C = d_C_full;
+    return 0;
+}
+
+int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
+{
+    if (!good(d) || !key) return MI_SPMM_EINVAL;
+    const std::string k(key);
+    if (k == "exchange") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; d->exchange = (int)v; }
+    else if (k == "n_panels") {
+        if (v < 1 || v > (1 << 20)) return MI_SPMM_EINVAL;
+        (void)hipDeviceSynchronize();   // staging buffers of a step in flight
+        d->n_panels = (int32_t)v;
+        make_panels(d);
+        free_staging(d);
+        d->unpacked_valid[0] = d->unpacked_valid[1] = false;
+    } else return MI_SPMM_EUNSUPPORTED;
+    return 0;
+}
+
+int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *value)
+{
+    if (!good(d) || !key || !value) return MI_SPMM_EINVAL;
+    const std::string k(key);
+    const int64_t moved = (int64_t)(d->world - 1) * d->M * (int64_t)d->n_loc * 4;
+    if (k == "exchange") *value = d->exchange;
+    else if (k == "n_panels") *value = (int64_t)d->panels.size();
+    else if (k == "world") *value = d->world;
+    else if (k == "rank") *value = d->rank;
+    else if (k == "has_comm") *value = d->comm ? 1 : 0;
+    else if (k == "has_peers") *value = (int)d->peer_C.size() == d->world ? 1 : 0;
+    else if (k == "staging_bytes") *value = (int64_t)(2 * d->staging_elems * sizeof(float));
+    else if (k == "bytes_sent_per_step") *value = moved;
+    else if (k == "bytes_received_per_step") *value = moved;
+    else return MI_SPMM_EUNSUPPORTED;
+    return 0;
+}
+
+int mi_spmm_dist_run(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, void *stream)
+{
+    return step(d, d_B_loc, d_C_full, (hipStream_t)stream, true, true);
+}
+
+int mi_spmm_dist_run_compute_only(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, void *stream)
+{
+    return step(d, d_B_loc, d_C_full, (hipStream_t)stream, true, false);
+}
+
+int mi_spmm_dist_run_exchange_only(mi_spmm_dist *d, float *d_C_full, void *stream)
+{
+    return step(d, nullptr, d_C_full, (hipStream_t)stream, false, true);
+}
+
+const char *mi_spmm_dist_strerror(int code)
+{
+    if (code <= MI_SPMM_DIST_ENCCL_BASE) return ncclGetErrorString((ncclResult_t)(MI_SPMM_DIST_ENCCL_BASE - code));
+    return mi_spmm_strerror(code);
+}
+
+}  // extern "C"

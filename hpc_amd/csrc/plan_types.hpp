@@ -23,6 +23,7 @@ struct LongRow {
 
 // ---- block (MFMA) path ---------------------------------------------------------------------------
 constexpr int kMaxPieces = 4;     // most pieces (= passes) a group's column list is cut into
+constexpr int kShareLenUnit = 16; // a run piece is shared only if its length is a multiple of this (the kernels' largest k batch)
 
 struct GroupPieces {              // analyze_group_runs output, one per qualifying group (64 bytes)
     int32_t n;                    // pieces: 1..kMaxPieces
@@ -34,18 +35,23 @@ struct GroupPieces {              // analyze_group_runs output, one per qualifyi
 
 enum : int32_t { kPieceCarryIn = 1, kPieceCarryOut = 2 };
 
-struct BlockPiece {               // one piece of one group, as the kernel sees it
+constexpr int kMaxShare = 2;      // most pieces per item = widest block kernel instantiated (spmm_block_items<.., G, ..>)
+
+struct BlockPiece {               // one piece of one group, as the kernel sees it (24 bytes)
     int32_t group;                // 16-row group index (rows 16*group .. 16*group+15)
     int32_t k0;                   // first position of the piece inside each row
     int32_t len;                  // nonzeros per row in the piece
     int32_t flags;                // kPieceCarryIn: the chain continues from C; kPieceCarryOut: a later pass continues it
+    int32_t p0;                   // row_ptr[16*group]: the group's 16 rows are p0 + i*row_len (equal lengths: they qualified)
+    int32_t row_len;              // nonzeros per row of the group (the whole list, not the piece)
 };
 
-struct BlockItem {                // what one wave sweeps: up to G pieces sharing their B rows (longest first)
-    int32_t first;                // index of its first piece in the pieces array
-    int32_t m;                    // pieces
-    int32_t c0;                   // >= 0: B rows c0, c0+1, ...; < 0: the columns are read from col_idx (m == 1)
-    int32_t len_max;              // length of the longest (= first) piece
+struct BlockItem {                // what one wave sweeps: up to kMaxShare pieces sharing their B rows, longest first.
+    int32_t m;                    // pieces                       One 64-byte record = one memory round trip before
+    int32_t c0;                   // run items: B rows c0, c0+1, ...; list items: < 0        the first B row is requested.
+    BlockPiece p[kMaxShare];
+    int32_t pad[2];
 };
+static_assert(sizeof(BlockItem) == 64, "one item = one 64-byte record");
 
 }  // namespace mi

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "plan_types.hpp"
 
 namespace mi {
@@ -557,7 +559,6 @@ __global__ __launch_bounds__(kBlockThreads) void detect_row_blocks(const int32_t
 // the sweep of its first run's neighbourhood.
 struct BlockArgs {
     const BlockItem *items;
-    const BlockPiece *pieces;
     const int32_t *row_ptr;
     const int32_t *col_idx;
     const float *vals;
@@ -592,11 +593,17 @@ __device__ __forceinline__ void wave_lds_sync()
 // operand land on disjoint banks) -> per 4-k step ONE ds_read_b32 per tile feeding up to G MFMAs (one per
 // piece, each with its own A fragment and accumulators).  The next batch's global loads are issued before
 // the current batch's MFMAs.  Pieces of an item are ordered longest first and every shared piece's length
-// is a multiple of 4, so at any k-step the first `nact` pieces are active and no step is partial for a
-// piece that is not the longest (a partial step multiplies zero-filled B rows by zero A values: exact no-op).
-template <int TILES, int G, bool WIDE>
+// is a multiple of kShareLenUnit (a whole number of batches), so the k loop is two plain loops: the batches in
+// which both pieces run, then the longest piece's remainder alone.  Only the longest piece can end inside a
+// batch (that batch multiplies zero-filled B rows by zero A values: exact no-ops) -- a shorter piece never meets
+// the longer one's extra B rows, so an inf or NaN there cannot reach it.
+// RUN: the launch's items are column runs (B rows c0, c0+1, ...: no column indices are read at run time);
+// !RUN: column lists (one piece per item).  Separate instantiations: one prefetch form per kernel keeps the k loop
+// free of the other form's branches and registers.
+template <int TILES, int G, bool WIDE, bool RUN>
 __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) void spmm_block_items(BlockArgs a)
 {
+    static_assert(RUN || G == 1, "list items hold one piece");
     constexpr int NS = 16 * TILES;        // slab width in floats
     constexpr int LPRB = NS / 4;          // lanes per B row (16 B each)
     constexpr int RPI = 64 / LPRB;        // B rows per load instruction
@@ -618,26 +625,25 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
     const int colv = slab0 + 4 * (lane % LPRB);    // first of this lane's 4 columns
     const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colv * 4u;
 
-    const BlockItem item = a.items[ii];
-    const int m = __builtin_amdgcn_readfirstlane(item.m);
-    const int first = __builtin_amdgcn_readfirstlane(item.first);
-    const int c0 = __builtin_amdgcn_readfirstlane(item.c0);   // >= 0: the pieces are the column run c0, c0+1, ...; < 0: a column list
-    int pg[G], pk0[G], plen[G], pfl[G];
+    // the item record: 16 dwords, one per lane, then broadcast (one memory round trip)
+    static_assert(G <= kMaxShare, "item records hold kMaxShare pieces");
+    const int32_t rec = reinterpret_cast<const int32_t *>(a.items + ii)[lane & 15];
+    const int m = __builtin_amdgcn_readlane(rec, 0);
+    const int c0 = __builtin_amdgcn_readlane(rec, 1);   // run items: the pieces are the column run c0, c0+1, ...
+    int pg[G], pk0[G], plen[G], pfl[G], pp0[G], prl[G];
     bool inr[G];
     int n_in = 0;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-        pg[j] = pk0[j] = plen[j] = pfl[j] = 0;
-        inr[j] = false;
-        if (j < m) {
-            const BlockPiece p = a.pieces[first + j];
-            pg[j] = __builtin_amdgcn_readfirstlane(p.group);
-            pk0[j] = __builtin_amdgcn_readfirstlane(p.k0);
-            plen[j] = __builtin_amdgcn_readfirstlane(p.len);
-            pfl[j] = __builtin_amdgcn_readfirstlane(p.flags);
-            inr[j] = !((pg[j] << 4) + 16 <= a.row_lo || (pg[j] << 4) >= a.row_hi);
-            n_in += inr[j] ? 1 : 0;
-        }
+        pg[j] = __builtin_amdgcn_readlane(rec, 2 + 6 * j);
+        pk0[j] = __builtin_amdgcn_readlane(rec, 3 + 6 * j);
+        plen[j] = __builtin_amdgcn_readlane(rec, 4 + 6 * j);
+        pfl[j] = __builtin_amdgcn_readlane(rec, 5 + 6 * j);
+        pp0[j] = __builtin_amdgcn_readlane(rec, 6 + 6 * j);
+        prl[j] = __builtin_amdgcn_readlane(rec, 7 + 6 * j);
+        inr[j] = j < m && !((pg[j] << 4) + 16 <= a.row_lo || (pg[j] << 4) >= a.row_hi);
+        if (!(j < m)) plen[j] = 0;
+        n_in += inr[j] ? 1 : 0;
     }
     if (n_in == 0) return;
     // every piece inside the row range (always, unless the caller runs row panels): one shared sweep.
@@ -653,33 +659,119 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
     static_assert(16 * LDT <= KT * SLD, "epilogue tile must fit the staging slice");
 
     for (int rep = 0; rep < nrep; ++rep) {
-        int np, sg[G], sk0[G], slen[G], sfl[G];
+        int np, sg[G], sk0[G], slen[G], sfl[G], sp0[G], srl[G];
         if (together) {
             np = m;
 #pragma unroll
-            for (int j = 0; j < G; ++j) { sg[j] = pg[j]; sk0[j] = pk0[j]; slen[j] = plen[j]; sfl[j] = pfl[j]; }
+            for (int j = 0; j < G; ++j) { sg[j] = pg[j]; sk0[j] = pk0[j]; slen[j] = plen[j]; sfl[j] = pfl[j]; sp0[j] = pp0[j]; srl[j] = prl[j]; }
         } else {
             np = 1;
             bool ok = inr[0];
-            sg[0] = pg[0]; sk0[0] = pk0[0]; slen[0] = plen[0]; sfl[0] = pfl[0];
+            sg[0] = pg[0]; sk0[0] = pk0[0]; slen[0] = plen[0]; sfl[0] = pfl[0]; sp0[0] = pp0[0]; srl[0] = prl[0];
 #pragma unroll
             for (int j = 1; j < G; ++j) {
-                if (rep == j) { ok = inr[j]; sg[0] = pg[j]; sk0[0] = pk0[j]; slen[0] = plen[j]; sfl[0] = pfl[j]; }
-                sg[j] = sk0[j] = slen[j] = sfl[j] = 0;
+                if (rep == j) { ok = inr[j]; sg[0] = pg[j]; sk0[0] = pk0[j]; slen[0] = plen[j]; sfl[0] = pfl[j]; sp0[0] = pp0[j]; srl[0] = prl[j]; }
+                sg[j] = sk0[j] = slen[j] = sfl[j] = sp0[j] = srl[j] = 0;
             }
             if (!ok) continue;
         }
         const int L = slen[0];                       // the longest piece: B rows c0 .. c0+L-1 (or the L listed columns)
-        int rowstart[G];                             // this lane's row of piece j: first value of the piece
+        int rowstart[G];                             // this lane's row of piece j: first value of the piece (the group's rows have equal lengths)
 #pragma unroll
-        for (int j = 0; j < G; ++j) rowstart[j] = (j < np) ? a.row_ptr[(sg[j] << 4) + i16] + sk0[j] : 0;
-        const int list0 = __builtin_amdgcn_readfirstlane(a.row_ptr[sg[0] << 4]) + sk0[0];   // list mode: where the piece's columns are stored
+        for (int j = 0; j < G; ++j) rowstart[j] = sp0[j] + i16 * srl[j] + sk0[j];
+        const int list0 = sp0[0] + sk0[0];           // list items: where the piece's columns are stored (row 0 of the group)
 
         float4a acc[G][TILES];
 #pragma unroll
         for (int j = 0; j < G; ++j)
 #pragma unroll
             for (int t = 0; t < TILES; ++t) acc[j][t] = (float4a){0.f, 0.f, 0.f, 0.f};
+        float4v R[LOADS];
+        float af[G][KS];
+        // A values of batch kb: lane (i16, kq) holds A[row i16][k = kb + 4s + kq] of every piece
+        auto fetch_a = [&](int kb) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int k = kb + 4 * s + kq;
+                    af[j][s] = (j < np && k < slen[j]) ? a.vals[rowstart[j] + k] : 0.f;
+                }
+        };
+        // run items, whole batch inside the run: 8 unconditional loads of rows c0 + kb + ..
+        auto prefetch_run_full = [&](int kb) {
+#pragma unroll
+            for (int u = 0; u < LOADS; ++u)
+                R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + u * RPI + q_in));
+            fetch_a(kb);
+        };
+        // list items: column indices run one batch ahead of the B rows they address (cj_next holds batch kb's
+        // indices when prefetch(kb) is called), so a prefetch is one memory round trip, not two dependent ones
+        int cj_next = (!RUN && lane < KT && lane < L) ? a.col_idx[list0 + lane] : 0;
+        auto prefetch = [&](int kb) {
+            if (!RUN) {
+                const int cj = cj_next;
+                const int kk = kb + KT + lane;
+                cj_next = (lane < KT && kk < L) ? a.col_idx[list0 + kk] : 0;
+#pragma unroll
+                for (int u = 0; u < LOADS; ++u) {
+                    const int j = u * RPI + q_in;
+                    const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
+                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
+                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < LOADS; ++u) {
+                    const int j = u * RPI + q_in;
+                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
+                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + j));
+                }
+            }
+            fetch_a(kb);
+        };
+        auto prefetch_any = [&](int kb) {
+            if (RUN && kb + KT <= L) prefetch_run_full(kb);
+            else prefetch(kb);
+        };
+
+        // One batch: registers -> LDS (rows past L were zero-filled: 0 * 0 terms are exact no-ops), the next
+        // batch's loads, then KS k-steps in which every B operand read from LDS feeds NA MFMAs (pieces 0..NA-1).
+        auto batch = [&](auto na_tag, int kb) {
+            constexpr int NA = decltype(na_tag)::value;
+            wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < LOADS; ++u) {
+                const int j = u * RPI + q_in;
+                *reinterpret_cast<float4v *>(lds + j * SLD + 4 * (lane % LPRB)) = R[u];
+            }
+            float acur[NA][KS];
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acur[j][s] = af[j][s];
+            wave_lds_sync();
+            if (kb + KT < L) prefetch_any(kb + KT);
+            // the B operands of TB tiles are read from LDS together (one wait), then feed NA MFMAs each
+            constexpr int TB = TILES < 8 ? TILES : 8;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int t0 = 0; t0 < TILES; t0 += TB) {
+                    float bv[TB];
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) bv[t] = lds[(4 * s + kq) * SLD + 16 * (t0 + t) + i16];
+#pragma unroll
+                    for (int t = 0; t < TB; ++t)
+#pragma unroll
+                        for (int j = 0; j < NA; ++j)
+                            acc[j][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j][s], bv[t], acc[j][t0 + t], 0, 0, 0);
+                }
+            }
+        };
+
+        // the first batch's loads are in flight while a continued chain's tile comes back from C
+        prefetch_any(0);
         // pieces after a group's first continue the chain pass p-1 left in C
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -706,111 +798,15 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
             }
         }
 
-        float4v R[LOADS];
-        float af[G][KS];
-        // A values of batch kb: lane (i16, kq) holds A[row i16][k = kb + 4s + kq] of every piece
-        auto fetch_a = [&](int kb) {
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int k = kb + 4 * s + kq;
-                    af[j][s] = (j < np && k < slen[j]) ? a.vals[rowstart[j] + k] : 0.f;
-                }
-        };
-        // run mode, whole batch inside the run: 8 unconditional loads of rows c0 + kb + ..
-        auto prefetch_run_full = [&](int kb) {
-#pragma unroll
-            for (int u = 0; u < LOADS; ++u)
-                R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + u * RPI + q_in));
-            fetch_a(kb);
-        };
-        // list mode: column indices run one batch ahead of the B rows they address (cj_next holds batch kb's
-        // indices when prefetch(kb) is called), so a prefetch is one memory round trip, not two dependent ones
-        int cj_next = (c0 < 0 && lane < KT && lane < L) ? a.col_idx[list0 + lane] : 0;
-        auto prefetch = [&](int kb) {
-            const int cj = cj_next;
-            if (c0 < 0) {
-                const int kk = kb + KT + lane;
-                cj_next = (lane < KT && kk < L) ? a.col_idx[list0 + kk] : 0;
-#pragma unroll
-                for (int u = 0; u < LOADS; ++u) {
-                    const int j = u * RPI + q_in;
-                    const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
-                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < LOADS; ++u) {
-                    const int j = u * RPI + q_in;
-                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + j));
-                }
-            }
-            fetch_a(kb);
-        };
-        auto prefetch_any = [&](int kb) {
-            if (c0 >= 0 && kb + KT <= L) prefetch_run_full(kb);
-            else prefetch(kb);
-        };
-
         wave_lds_sync();
-        prefetch_any(0);
-        for (int kb = 0; kb < L; kb += KT) {
-            // registers -> LDS (rows past L were zero-filled: 0 * 0 terms are exact no-ops)
-            wave_lds_sync();
-#pragma unroll
-            for (int u = 0; u < LOADS; ++u) {
-                const int j = u * RPI + q_in;
-                *reinterpret_cast<float4v *>(lds + j * SLD + 4 * (lane % LPRB)) = R[u];
-            }
-            float acur[G][KS];
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acur[j][s] = af[j][s];
-            wave_lds_sync();
-            if (kb + KT < L) prefetch_any(kb + KT);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int k = kb + 4 * s;
-                if (G == 1 || np == 1 || k >= slen[G > 1 ? 1 : 0]) {
-                    // only the longest piece is active in this step (k < L may be false in the last batch: zero rows, zero values)
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t) {
-                        const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-                        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][s], b, acc[0][t], 0, 0, 0);
-                    }
-                } else {
-                    int nact = 2;
-#pragma unroll
-                    for (int j = 2; j < G; ++j) nact += (j < np && k < slen[j]) ? 1 : 0;
-                    if (G == 2 || nact == 2) {
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-                            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][s], b, acc[0][t], 0, 0, 0);
-                            acc[G > 1 ? 1 : 0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[G > 1 ? 1 : 0][s], b, acc[G > 1 ? 1 : 0][t], 0, 0, 0);
-                        }
-                    } else if (G == 3 || nact == 3) {
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-#pragma unroll
-                            for (int j = 0; j < (G < 3 ? G : 3); ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j][s], b, acc[j][t], 0, 0, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t) {
-                            const float b = lds[(4 * s + kq) * SLD + 16 * t + i16];
-#pragma unroll
-                            for (int j = 0; j < G; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j][s], b, acc[j][t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+        // pieces are ordered longest first and a shared piece's length is a multiple of the batch (kShareLenUnit):
+        // first the batches in which both pieces run, then the longest piece's remainder on its own
+        int kb = 0;
+        if (G >= 2) {
+            const int l1 = (np >= 2) ? slen[G >= 2 ? 1 : 0] : 0;
+            for (; kb < l1; kb += KT) batch(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, kb);
         }
+        for (; kb < L; kb += KT) batch(std::integral_constant<int, 1>{}, kb);
         // Epilogue.  D reg q of lane l is C[r0 + 4*kq + q][slab0 + 16t + i16]: stored directly that is 4-byte
         // elements in 64-byte runs (64 store instructions per lane, 30 % write amplification).  Instead each
         // tile goes through the wave's LDS slice, at most 128 columns at a time, and leaves as whole
@@ -818,7 +814,8 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (j < np) {
-                const int r0 = sg[j] << 4;
+                int r0 = sg[j] << 4;
+                asm volatile("" : "+s"(r0));   // the row addresses below are computed here, not hoisted above the k loop (registers)
                 const bool carried = (sfl[j] & kPieceCarryOut) != 0;
 #pragma unroll
                 for (int h = 0; h < TILES / EH; ++h) {

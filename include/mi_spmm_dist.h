@@ -1,0 +1,91 @@
+/*
+ * mi_spmm_dist.h -- C ABI of the column-sharded multi-GPU step (hpc_amd/libmi_spmm_dist.so).
+ *
+ *     C[:, g*n : (g+1)*n] = A * B[:, g*n : (g+1)*n]   on GPU g of G,   then every rank holds row-major C[M][G*n].
+ *
+ * The reference has no multi-GPU code: its only trace is the commented-out `extern ncclComm_t comm;` of
+ * PA4/workspace/include/util.h:30.  This library is what that line would have grown into -- the exchange of
+ * the C column blocks over RCCL / xGMI (BASELINE.json north_star) behind plain C entry points, so
+ * that the reference's own C++ harness (one process per GPU, MPI or any launcher) reaches the N > 1 path:
+ * no torch, no Python in the signatures.  It is a separate library: libmi_spmm.so (the operator) stays free
+ * of any communication dependency; this one links librccl.
+ *
+ * One process per GPU.  A (the CSR arrays of the mi_spmm handle) is replicated, the rank's B slice is a
+ * contiguous K x n_loc array, C_full is the caller's row-major M x (world*n_loc) array on every rank.
+ * A step is pipelined by row panels over three streams (compute / exchange / re-layout).
+ *
+ * Exchange schedules ("exchange" option):
+ *   0  allgather  ncclAllGather of the panel's column blocks into rank-major staging, then a re-layout
+ *                 kernel into C_full (an all-gather concatenates contiguous per-rank buffers).
+ *                 The rank computes its own block straight into its staging slot (in-place all-gather).
+ *   1  direct     the same staging layout filled by ONE grouped launch of world-1 ncclSend of the rank's block and
+ *                 world-1 ncclRecv straight into staging[peer]: on a fully connected node every pair has its own
+ *                 xGMI link, so all links of a GPU carry one block each at the same time.
+ *   2  peer2d     no staging, no re-layout: the rank computes its block straight into ITS C_full (row pitch
+ *                 world*n_loc) and pushes the panel into every peer's C_full with a strided 2-D device-to-device
+ *                 copy (512-byte row segments at pitch 4*N_total; the peers' C_full are mapped through HIP IPC).
+ *                 Per step and GPU this moves (world-1)/world of C once out and once in, and nothing else.
+ * 0 and 1 need a communicator (mi_spmm_dist_comm_init); 2 needs the peers' C_full (mi_spmm_dist_set_peers) and,
+ * to be self-synchronising, a communicator too (a one-element all-reduce is the end-of-step barrier); without
+ * one the caller must put a cross-rank barrier after the step's stream work and before the next step.
+ *
+ * Errors: 0 = ok; negative MI_SPMM_E* codes of mi_spmm.h; positive hipError_t; ncclResult_t r is returned as
+ * MI_SPMM_DIST_ENCCL_BASE - r.  Never aborts.
+ */
+#ifndef MI_SPMM_DIST_H
+#define MI_SPMM_DIST_H
+
+#include <stdint.h>
+
+#include "mi_spmm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_SPMM_DIST_ENCCL_BASE (-1000)
+#define MI_SPMM_DIST_UNIQUE_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+#define MI_SPMM_DIST_IPC_HANDLE_BYTES 64   /* sizeof(hipIpcMemHandle_t) */
+
+typedef struct mi_spmm_dist mi_spmm_dist;
+
+/* h: a PREPROCESSED operator for this rank's n_loc = feat_in columns (mi_spmm_preprocess done); it stays owned by
+ * the caller and must outlive the object.  n_panels: row panels per step (>= 1; panels are multiples of 256 rows). */
+int mi_spmm_dist_create(mi_spmm_dist **out, mi_spmm_handle *h, int32_t num_v, int32_t n_loc, int32_t rank,
+                        int32_t world, int32_t n_panels);
+int mi_spmm_dist_destroy(mi_spmm_dist *d);
+
+/* Communicator bootstrap, the usual RCCL way: rank 0 fills 128 bytes (ncclGetUniqueId), the host launcher
+ * broadcasts them (MPI_Bcast, a file, torch.distributed ...), every rank calls comm_init (collective).
+ * mi_spmm_dist_set_comm adopts a communicator the host already has instead (ncclComm_t; not destroyed by us). */
+int mi_spmm_dist_unique_id(void *id_out);
+int mi_spmm_dist_comm_init(mi_spmm_dist *d, const void *id);
+int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm);
+
+/* peer2d: export this rank's C_full (64-byte HIP IPC handle + the byte offset of d_C_full inside its
+ * allocation), all-gather handles and offsets on the host side, hand the tables in.  handles: world x 64 bytes,
+ * offsets: world x int64; the rank's own entry is ignored.  Re-call when C_full changes. */
+int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out);
+int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
+
+/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d), "n_panels"; read-only: "world", "rank", "has_comm",
+ * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step" */
+int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);
+int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *value);
+
+/* One step.  d_B_loc: K x n_loc (pitch n_loc); d_C_full: M x (world*n_loc) (pitch world*n_loc), the same
+ * pointer that was exported for peer2d.  Asynchronous: everything is ordered after the work already on `stream`,
+ * and `stream` waits for the step's exchange at the end.  world == 1: the block IS C. */
+int mi_spmm_dist_run(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, void *stream);
+
+/* The two legs on their own, for the reported breakdown (bench.py): compute-only writes the rank's block into its
+ * staging slot / C_full; exchange-only moves whatever the block holds. */
+int mi_spmm_dist_run_compute_only(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, void *stream);
+int mi_spmm_dist_run_exchange_only(mi_spmm_dist *d, float *d_C_full, void *stream);
+
+const char *mi_spmm_dist_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SPMM_DIST_H */
