@@ -195,7 +195,10 @@ static int build_block_items(mi_spmm_handle *h)
                 p.row_len = len16[(size_t)keys[q].gi];
                 ++n_pieces;
             }
-            (it.c0 < 0 ? lists : it.m > 1 ? shared : singles).push_back(it);
+            // run items of one and of two pieces go through the same launch where the two-piece kernels exist: one long
+            // list in column order instead of two short ones (a short launch pays its tail on 256 CUs)
+            (it.c0 < 0 ? lists : (it.m > 1 || share > 1) ? shared : singles).push_back(it);
+            if (it.m > 1) ++n_shared;
             i = j;
         }
         std::vector<BlockItem> *cls[3] = {&lists, &singles, &shared};
@@ -204,7 +207,6 @@ static int build_block_items(mi_spmm_handle *h)
             h->blk_launch[pass][c].n = (int32_t)cls[c]->size();
             items.insert(items.end(), cls[c]->begin(), cls[c]->end());
         }
-        n_shared += (int32_t)shared.size();
     }
     if (items.empty()) return MI_SPMM_OK;
     if (hipMalloc((void **)&h->d_blk_items, items.size() * sizeof(BlockItem)) != hipSuccess) return MI_SPMM_ENOMEM;
@@ -741,11 +743,12 @@ void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s, in
 template <int G, bool WIDE, bool RUN>
 void launch_block_items_g(int slab, const BlockArgs &a, dim3 grid, hipStream_t s)
 {
-    // shared items (G > 1) exist only for slabs of 256 or 128 columns (N % 128 == 0); narrower N runs every item alone
-    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<16, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<8, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<4, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<2, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    // slab = columns one wave covers: 256 / 128 / 64 as 4 / 2 / 1 chunks of 64 (16 bytes per lane), 32 as one chunk of
+    // 32 (8 bytes per lane).  Shared items (G > 1) exist only for 256 and 128 (N % 128 == 0).
+    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<4, 4, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<2, 4, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<1, 4, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<1, 2, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
 }
 // cls: 0 = list items, 1 = run items holding one piece, 2 = run items sharing their B rows between two pieces
 void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
@@ -856,7 +859,6 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
                              ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
     if (blocks_on && launch_blocks_here) {
         BlockArgs ba;
-        ba.row_ptr = h->d_ptr;
         ba.col_idx = h->d_idx;
         ba.vals = h->d_val;
         ba.B = full.B;

@@ -23,7 +23,7 @@ struct LongRow {
 
 // ---- block (MFMA) path ---------------------------------------------------------------------------
 constexpr int kMaxPieces = 4;     // most pieces (= passes) a group's column list is cut into
-constexpr int kShareLenUnit = 16; // a run piece is shared only if its length is a multiple of this (the kernels' largest k batch)
+constexpr int kShareLenUnit = 32; // a run piece is shared only if its length is a multiple of this (two of the kernels' largest k batches)
 
 struct GroupPieces {              // analyze_group_runs output, one per qualifying group (64 bytes)
     int32_t n;                    // pieces: 1..kMaxPieces

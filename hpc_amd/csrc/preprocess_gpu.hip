@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "../../include/mi_spmm.h"
 
 namespace mi {
@@ -183,7 +186,12 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     if (d_col_bad) PLAN_TRY(hipMemcpyAsync(&host.col_bad, d_col_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, 0));
     PLAN_TRY(hipStreamSynchronize(0));
     // data.cu:40-45 asserts ptr[num_v] == num_e; monotone rows and in-range columns keep the kernels in bounds
-    if (host.st.bad || host.col_bad || (int64_t)host.st.ptrM != nnz || host.st.ptr0 < 0) return MI_SPMM_ECSR;
+    if (host.st.bad || host.col_bad || (int64_t)host.st.ptrM != nnz || host.st.ptr0 < 0) {
+        if (getenv("MI_SPMM_DEBUG"))
+            fprintf(stderr, "mi_spmm: CSR rejected: negative-length/ptr0 bits %u, column out of range %u, row_ptr[0] = %d, row_ptr[M] = %d, nnz = %lld\n",
+                    host.st.bad, host.col_bad, host.st.ptr0, host.st.ptrM, (long long)nnz);
+        return MI_SPMM_ECSR;
+    }
     out->max_len = host.st.max_len;
     out->mthr = host.st.mthr;
     out->n_chunks = host.n_chunks;

@@ -553,13 +553,12 @@ __global__ __launch_bounds__(kBlockThreads) void detect_row_blocks(const int32_t
 // +0, pass p > 0 CONTINUES them from the 16 x N tile pass p-1 left in C -- the accumulator of an f32 MFMA
 // chain is an ordinary f32, so storing it and loading it back changes no bit and the k order of every output
 // element is still the stored order.  Why bother: inside one pass the pieces are sorted by their first column
-// and pieces that are the same run [c0, c0+len) of different groups form one ITEM: its B rows are staged
-// through LDS once and feed every piece's MFMAs (reuse 16*m rows per B row instead of 16), and neighbouring
-// items touch neighbouring B rows on one XCD.  A group's second run no longer drags a random B range into
-// the sweep of its first run's neighbourhood.
+// and pieces that are the same run [c0, c0+len) of different groups form one ITEM: its B rows are fetched
+// once and feed every piece's MFMAs (reuse 16*m rows per B row instead of 16), and neighbouring items touch
+// neighbouring B rows on one XCD.  A group's second run no longer drags a random B range into the sweep of its
+// first run's neighbourhood.
 struct BlockArgs {
     const BlockItem *items;
-    const int32_t *row_ptr;
     const int32_t *col_idx;
     const float *vals;
     const float *B;
@@ -573,60 +572,54 @@ struct BlockArgs {
 };
 
 typedef float float4a __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 
-// Lanes of a wave that exchange data through their private LDS slice: order the
-// compiler's view of the accesses (the hardware executes one wave's LDS
-// instructions in order, so no counter wait is needed for visibility).
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+template <int V> struct BVec;
+template <> struct BVec<4> { typedef float4v T; };
+template <> struct BVec<2> { typedef float2v T; };
 
-// One wave per item and 16*TILES-column slab (blockIdx.y = slab); G = most pieces an item of this launch holds.
+// One wave per item and slab of XC chunks (blockIdx.y = slab); a chunk is 16*V columns; G = most pieces an item
+// of this launch holds.  No LDS anywhere: the loads are shaped like the MFMA operands.
 //   v_mfma_f32_16x16x4_f32: A lane l = A[i = l&15][k = l>>4], B lane l = B[k = l>>4][j = l&15],
-//   D reg q of lane l = D[row 4*(l>>4)+q][col l&15]; the result is a k-ordered fp32 fma chain,
-//   so with k ascending per output element the block path is bit-identical to the rows path.
-// Per batch of KT k-rows: 8 x global_load_dwordx4 (8 KiB of B, full rows, coalesced) -> registers
-// -> ds_write_b128 into the wave's LDS slice (row pitch N_slab+16 floats: the 4 k-rows of an MFMA
-// operand land on disjoint banks) -> per 4-k step ONE ds_read_b32 per tile feeding up to G MFMAs (one per
-// piece, each with its own A fragment and accumulators).  The next batch's global loads are issued before
-// the current batch's MFMAs.  Pieces of an item are ordered longest first and every shared piece's length
-// is a multiple of kShareLenUnit (a whole number of batches), so the k loop is two plain loops: the batches in
-// which both pieces run, then the longest piece's remainder alone.  Only the longest piece can end inside a
-// batch (that batch multiplies zero-filled B rows by zero A values: exact no-ops) -- a shorter piece never meets
-// the longer one's extra B rows, so an inf or NaN there cannot reach it.
-// RUN: the launch's items are column runs (B rows c0, c0+1, ...: no column indices are read at run time);
-// !RUN: column lists (one piece per item).  Separate instantiations: one prefetch form per kernel keeps the k loop
-// free of the other form's branches and registers.
-template <int TILES, int G, bool WIDE, bool RUN>
-__global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) void spmm_block_items(BlockArgs a)
+//   D reg q of lane l = D[row 4*(l>>4)+q][col l&15]; the result is a k-ordered fp32 fma chain, so with k
+//   ascending per output element the block path is bit-identical to the rows path.
+// A tile's 16 columns need not be adjacent: tile (x, e) is the columns  16V*x + V*i + e  (i = 0..15) of the slab.
+// Then ONE global_load_dwordx4 per lane -- lane (kq, i16) reads B[row k0 + kq][64x + 4*i16 .. +3]: four 256-byte
+// segments per instruction, whole cache lines -- delivers the B operands of the four tiles (x, 0..3) of one
+// k-step straight into registers, and register q of the four accumulators (x, 0..3) is the float4
+// C[row 4*kq + q][64x + 4*i16 .. +3]: stores (and the loads of a continued chain) are 16 bytes per lane in
+// 256-byte row segments as well.  Per batch: 8 such loads (XC per k-step) + G A-operand dwords per k-step,
+// TWO batches in flight (two register sets), 8*V*G MFMAs per batch.
+// Pieces of an item are ordered longest first and every shared piece's length is a multiple of
+// kShareLenUnit (a whole number of batch pairs), so the k loop is two plain loops: the batches in which both
+// pieces run, then the longest piece's remainder alone.  Only the longest piece can end inside a batch (its
+// missing rows are zero B operands times zero A operands: exact no-ops) -- a shorter piece never meets the
+// longer one's extra B rows, so an inf or NaN there cannot reach it.
+template <int XC, int V, int G, bool WIDE, bool RUN>
+__global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a)
 {
     static_assert(RUN || G == 1, "list items hold one piece");
-    constexpr int NS = 16 * TILES;        // slab width in floats
-    constexpr int LPRB = NS / 4;          // lanes per B row (16 B each)
-    constexpr int RPI = 64 / LPRB;        // B rows per load instruction
-    constexpr int LOADS = 8;
-    constexpr int KT = LOADS * RPI;       // k-rows per batch
-    constexpr int KS = KT / 4;            // MFMA k-steps per batch
-    constexpr int SLD = NS + 16;          // LDS row pitch (floats), == 16 mod 32
-    __shared__ __attribute__((aligned(16))) float lds_all[4 * KT * SLD];
+    static_assert(G <= kMaxShare, "item records hold kMaxShare pieces");
+    typedef typename BVec<V>::T BV;
+    constexpr int TILES = XC * V;         // 16-column tiles per slab
+    constexpr int CW = 16 * V;            // chunk width in floats
+    constexpr int NS = CW * XC;           // slab width in floats
+    constexpr int LOADS = 8;              // B loads per batch
+    constexpr int KS = LOADS / XC;        // MFMA k-steps per batch
+    constexpr int KT = 4 * KS;            // k-rows per batch
+    static_assert(G == 1 || kShareLenUnit % (2 * KT) == 0, "a shared piece must end on a batch-pair boundary");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vblk = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int ii = vblk * 4 + wave;
     if (ii >= a.n_items) return;          // wave-uniform (the kernel has no workgroup barrier)
-    float *lds = lds_all + wave * (KT * SLD);
     const int i16 = lane & 15, kq = lane >> 4;
     const int slab0 = (int)blockIdx.y * NS;
-    const int q_in = lane / LPRB;                  // which of the RPI rows of a load this lane serves
-    const int colv = slab0 + 4 * (lane % LPRB);    // first of this lane's 4 columns
+    const int colv = slab0 + V * i16;     // this lane's columns inside chunk 0; chunk x adds CW*x
     const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colv * 4u;
 
     // the item record: 16 dwords, one per lane, then broadcast (one memory round trip)
-    static_assert(G <= kMaxShare, "item records hold kMaxShare pieces");
     const int32_t rec = reinterpret_cast<const int32_t *>(a.items + ii)[lane & 15];
     const int m = __builtin_amdgcn_readlane(rec, 0);
     const int c0 = __builtin_amdgcn_readlane(rec, 1);   // run items: the pieces are the column run c0, c0+1, ...
@@ -650,13 +643,6 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
     // Otherwise the in-range pieces are swept one at a time.
     const bool together = (n_in == m);
     const int nrep = together ? 1 : m;
-
-    constexpr int EH = (TILES > 8) ? 8 : TILES;      // tiles per epilogue / prologue pass
-    constexpr int ENS = 16 * EH;                     // columns per pass
-    constexpr int LDT = ENS + 4;                     // pitch: rows 4 apart land 16 banks apart
-    constexpr int ELPR = ENS / 4;                    // lanes per row on the global side
-    constexpr int ERPI = 64 / ELPR;                  // rows per global instruction
-    static_assert(16 * LDT <= KT * SLD, "epilogue tile must fit the staging slice");
 
     for (int rep = 0; rep < nrep; ++rep) {
         int np, sg[G], sk0[G], slen[G], sfl[G], sp0[G], srl[G];
@@ -686,131 +672,112 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
         for (int j = 0; j < G; ++j)
 #pragma unroll
             for (int t = 0; t < TILES; ++t) acc[j][t] = (float4a){0.f, 0.f, 0.f, 0.f};
-        float4v R[LOADS];
-        float af[G][KS];
-        // A values of batch kb: lane (i16, kq) holds A[row i16][k = kb + 4s + kq] of every piece
-        auto fetch_a = [&](int kb) {
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int k = kb + 4 * s + kq;
-                    af[j][s] = (j < np && k < slen[j]) ? a.vals[rowstart[j] + k] : 0.f;
-                }
-        };
-        // run items, whole batch inside the run: 8 unconditional loads of rows c0 + kb + ..
-        auto prefetch_run_full = [&](int kb) {
-#pragma unroll
-            for (int u = 0; u < LOADS; ++u)
-                R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + u * RPI + q_in));
-            fetch_a(kb);
-        };
-        // list items: column indices run one batch ahead of the B rows they address (cj_next holds batch kb's
-        // indices when prefetch(kb) is called), so a prefetch is one memory round trip, not two dependent ones
-        int cj_next = (!RUN && lane < KT && lane < L) ? a.col_idx[list0 + lane] : 0;
-        auto prefetch = [&](int kb) {
-            if (!RUN) {
-                const int cj = cj_next;
-                const int kk = kb + KT + lane;
-                cj_next = (lane < KT && kk < L) ? a.col_idx[list0 + kk] : 0;
-#pragma unroll
-                for (int u = 0; u < LOADS; ++u) {
-                    const int j = u * RPI + q_in;
-                    const int c = (RPI == 1) ? __builtin_amdgcn_readlane(cj, u) : __shfl(cj, j, 64);
-                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < LOADS; ++u) {
-                    const int j = u * RPI + q_in;
-                    R[u] = (float4v){0.f, 0.f, 0.f, 0.f};
-                    if (kb + j < L) R[u] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c0 + kb + j));
-                }
-            }
-            fetch_a(kb);
-        };
-        auto prefetch_any = [&](int kb) {
-            if (RUN && kb + KT <= L) prefetch_run_full(kb);
-            else prefetch(kb);
-        };
-
-        // One batch: registers -> LDS (rows past L were zero-filled: 0 * 0 terms are exact no-ops), the next
-        // batch's loads, then KS k-steps in which every B operand read from LDS feeds NA MFMAs (pieces 0..NA-1).
-        auto batch = [&](auto na_tag, int kb) {
-            constexpr int NA = decltype(na_tag)::value;
-            wave_lds_sync();
-#pragma unroll
-            for (int u = 0; u < LOADS; ++u) {
-                const int j = u * RPI + q_in;
-                *reinterpret_cast<float4v *>(lds + j * SLD + 4 * (lane % LPRB)) = R[u];
-            }
-            float acur[NA][KS];
-#pragma unroll
-            for (int j = 0; j < NA; ++j)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acur[j][s] = af[j][s];
-            wave_lds_sync();
-            if (kb + KT < L) prefetch_any(kb + KT);
-            // the B operands of TB tiles are read from LDS together (one wait), then feed NA MFMAs each
-            constexpr int TB = TILES < 8 ? TILES : 8;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                for (int t0 = 0; t0 < TILES; t0 += TB) {
-                    float bv[TB];
-#pragma unroll
-                    for (int t = 0; t < TB; ++t) bv[t] = lds[(4 * s + kq) * SLD + 16 * (t0 + t) + i16];
-#pragma unroll
-                    for (int t = 0; t < TB; ++t)
-#pragma unroll
-                        for (int j = 0; j < NA; ++j)
-                            acc[j][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j][s], bv[t], acc[j][t0 + t], 0, 0, 0);
-                }
-            }
-        };
-
-        // the first batch's loads are in flight while a continued chain's tile comes back from C
-        prefetch_any(0);
-        // pieces after a group's first continue the chain pass p-1 left in C
+        // pieces after a group's first continue the chain pass p-1 left in C: register q of the tiles (x, 0..V-1) is
+        // the V floats C[r0 + 4*kq + q][slab0 + CW*x + V*i16 ..].  Ahead of the first B loads: the tile's loads need
+        // registers the two batch sets will occupy.
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (j < np && (sfl[j] & kPieceCarryIn)) {
                 const int r0 = sg[j] << 4;
 #pragma unroll
-                for (int h = 0; h < TILES / EH; ++h) {
-                    wave_lds_sync();
+                for (int q = 0; q < 4; ++q) {
+                    const int row = r0 + 4 * kq + q;
+                    const bool ok = row >= a.row_lo && row < a.row_hi;
 #pragma unroll
-                    for (int it = 0; it < 16 / ERPI; ++it) {
-                        const int row = it * ERPI + lane / ELPR;
-                        const int c4 = 4 * (lane % ELPR);
-                        float4v v = (float4v){0.f, 0.f, 0.f, 0.f};
-                        if (r0 + row >= a.row_lo && r0 + row < a.row_hi)
-                            v = *reinterpret_cast<const float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4);
-                        *reinterpret_cast<float4v *>(lds + row * LDT + c4) = v;
+                    for (int x = 0; x < XC; ++x) {
+                        BV v;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) v[e] = 0.f;
+                        if (ok) v = *reinterpret_cast<const BV *>(a.C + (int64_t)row * a.ldc + colv + CW * x);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[j][V * x + e][q] = v[e];
                     }
-                    wave_lds_sync();
-#pragma unroll
-                    for (int t = 0; t < EH; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[j][h * EH + t][q] = lds[(4 * kq + q) * LDT + 16 * t + i16];
                 }
             }
         }
 
-        wave_lds_sync();
-        // pieces are ordered longest first and a shared piece's length is a multiple of the batch (kShareLenUnit):
-        // first the batches in which both pieces run, then the longest piece's remainder on its own
-        int kb = 0;
-        if (G >= 2) {
-            const int l1 = (np >= 2) ? slen[G >= 2 ? 1 : 0] : 0;
-            for (; kb < l1; kb += KT) batch(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, kb);
+        // two register sets = two batches in flight.  Every float4 (float2) component is an MFMA B operand as it stands.
+        BV R0[LOADS], R1[LOADS];
+        float a0[G][KS], a1[G][KS];
+        int cn0[KS], cn1[KS];                        // list items: this lane's columns of the batch a set will hold next
+        // one batch into one register set.  Lane (kq, i16) serves k-row kb + 4s + kq of step s.  Straight-line code: rows
+        // past the end of the longest piece are fetched from its last row and zeroed (with a zero A operand: exact
+        // no-ops), so a set is always DEFINED by its fetch -- with a conditional fetch the register allocator kept a
+        // third and fourth copy of the sets and spilled them inside the k loop.
+        auto fetch = [&](BV (&R)[LOADS], float (&af)[G][KS], int (&cn)[KS], int kb) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k = kb + 4 * s + kq;
+                const bool live = k < L;
+                int c;
+                if (RUN) c = c0 + (live ? k : L - 1);
+                else {
+                    c = cn[s];                        // requested two batches ago (clamped the same way)
+                    const int k2 = k + 2 * KT;
+                    cn[s] = a.col_idx[list0 + (k2 < L ? k2 : L - 1)];
+                }
+                const float *rowp = b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c);   // chunk x = + CW*x: an immediate offset
+#pragma unroll
+                for (int x = 0; x < XC; ++x) {
+                    BV v = *reinterpret_cast<const BV *>(rowp + CW * x);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[e] = live ? v[e] : 0.f;
+                    R[s * XC + x] = v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int k = kb + 4 * s + kq;
+                    const bool live = j < np && k < slen[j];
+                    const float av = a.vals[rowstart[j] + (live ? k : 0)];
+                    af[j][s] = live ? av : 0.f;
+                }
+        };
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + kq;
+            cn0[s] = RUN ? 0 : a.col_idx[list0 + (k < L ? k : L - 1)];
+            cn1[s] = RUN ? 0 : a.col_idx[list0 + (k + KT < L ? k + KT : L - 1)];
         }
-        for (; kb < L; kb += KT) batch(std::integral_constant<int, 1>{}, kb);
-        // Epilogue.  D reg q of lane l is C[r0 + 4*kq + q][slab0 + 16t + i16]: stored directly that is 4-byte
-        // elements in 64-byte runs (64 store instructions per lane, 30 % write amplification).  Instead each
-        // tile goes through the wave's LDS slice, at most 128 columns at a time, and leaves as whole
-        // 16-byte-per-lane row segments.  A tile that a later pass continues stays cacheable; a final one is nt.
+        fetch(R0, a0, cn0, 0);
+        fetch(R1, a1, cn1, KT);
+
+        // the MFMAs of one batch: every B operand feeds NA pieces
+        auto compute = [&](auto na_tag, const BV (&R)[LOADS], const float (&af)[G][KS]) {
+            constexpr int NA = decltype(na_tag)::value;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int x = 0; x < XC; ++x)
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+#pragma unroll
+                        for (int j = 0; j < NA; ++j)
+                            acc[j][V * x + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], R[s * XC + x][e], acc[j][V * x + e], 0, 0, 0);
+        };
+        // Two batches per trip: set 0, refill set 0 for the batch after next, set 1, refill set 1.  A refill past the end
+        // of the piece (at most two per item) re-reads the last row and is never used.
+        int kb = 0;
+        if (G >= 2 && np >= 2) {
+            // both pieces run up to l1, a whole number of batch PAIRS (kShareLenUnit), l1 <= L
+            const int l1 = slen[G >= 2 ? 1 : 0];
+            for (; kb < l1; kb += 2 * KT) {
+                compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R0, a0);
+                fetch(R0, a0, cn0, kb + 2 * KT);
+                compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R1, a1);
+                fetch(R1, a1, cn1, kb + 3 * KT);
+            }
+        }
+        for (; kb < L; kb += 2 * KT) {
+            compute(std::integral_constant<int, 1>{}, R0, a0);
+            fetch(R0, a0, cn0, kb + 2 * KT);
+            compute(std::integral_constant<int, 1>{}, R1, a1);      // past the end: zero operands
+            fetch(R1, a1, cn1, kb + 3 * KT);
+        }
+        // Epilogue: register q of the tiles (x, 0..V-1) leaves as V floats per lane, 16 lanes = one 64V-byte row segment,
+        // four rows per store instruction.  A tile that a later pass continues stays cacheable; a final one is nt.
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (j < np) {
@@ -818,20 +785,15 @@ __global__ __launch_bounds__(kBlockThreads, (G > 1 ? 2 : (TILES >= 4 ? 4 : 3))) 
                 asm volatile("" : "+s"(r0));   // the row addresses below are computed here, not hoisted above the k loop (registers)
                 const bool carried = (sfl[j] & kPieceCarryOut) != 0;
 #pragma unroll
-                for (int h = 0; h < TILES / EH; ++h) {
-                    wave_lds_sync();
+                for (int q = 0; q < 4; ++q) {
+                    const int row = r0 + 4 * kq + q;
+                    if (row >= a.row_lo && row < a.row_hi) {
 #pragma unroll
-                    for (int t = 0; t < EH; ++t)
+                        for (int x = 0; x < XC; ++x) {
+                            BV v;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) lds[(4 * kq + q) * LDT + 16 * t + i16] = acc[j][h * EH + t][q];
-                    wave_lds_sync();
-#pragma unroll
-                    for (int it = 0; it < 16 / ERPI; ++it) {
-                        const int row = it * ERPI + lane / ELPR;
-                        const int c4 = 4 * (lane % ELPR);
-                        const float4v v = *reinterpret_cast<const float4v *>(lds + row * LDT + c4);
-                        if (r0 + row >= a.row_lo && r0 + row < a.row_hi) {
-                            float4v *dst = reinterpret_cast<float4v *>(a.C + (int64_t)(r0 + row) * a.ldc + slab0 + h * ENS + c4);
+                            for (int e = 0; e < V; ++e) v[e] = acc[j][V * x + e][q];
+                            BV *dst = reinterpret_cast<BV *>(a.C + (int64_t)row * a.ldc + colv + CW * x);
                             if (carried) *dst = v;
                             else __builtin_nontemporal_store(v, dst);
                         }
