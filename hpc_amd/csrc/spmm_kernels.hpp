@@ -679,19 +679,25 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
         for (int j = 0; j < G; ++j) {
             if (j < np && (sfl[j] & kPieceCarryIn)) {
                 const int r0 = sg[j] << 4;
+                // all loads first (rows outside the caller's range read a row inside it and are zeroed afterwards),
+                // so the 4*XC loads are in flight together: one round trip, not one per load
+                BV T[4][XC];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = r0 + 4 * kq + q;
+                    const int rowc = row < a.row_lo ? a.row_lo : (row >= a.row_hi ? a.row_hi - 1 : row);
+                    const float *cp = a.C + (int64_t)rowc * a.ldc + colv;
+#pragma unroll
+                    for (int x = 0; x < XC; ++x) T[q][x] = *reinterpret_cast<const BV *>(cp + CW * x);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = r0 + 4 * kq + q;
                     const bool ok = row >= a.row_lo && row < a.row_hi;
 #pragma unroll
-                    for (int x = 0; x < XC; ++x) {
-                        BV v;
+                    for (int x = 0; x < XC; ++x)
 #pragma unroll
-                        for (int e = 0; e < V; ++e) v[e] = 0.f;
-                        if (ok) v = *reinterpret_cast<const BV *>(a.C + (int64_t)row * a.ldc + colv + CW * x);
-#pragma unroll
-                        for (int e = 0; e < V; ++e) acc[j][V * x + e][q] = v[e];
-                    }
+                        for (int e = 0; e < V; ++e) acc[j][V * x + e][q] = ok ? T[q][x][e] : 0.f;
                 }
             }
         }
@@ -700,17 +706,17 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
         BV R0[LOADS], R1[LOADS];
         float a0[G][KS], a1[G][KS];
         int cn0[KS], cn1[KS];                        // list items: this lane's columns of the batch a set will hold next
-        // one batch into one register set.  Lane (kq, i16) serves k-row kb + 4s + kq of step s.  Straight-line code: rows
-        // past the end of the longest piece are fetched from its last row and zeroed (with a zero A operand: exact
-        // no-ops), so a set is always DEFINED by its fetch -- with a conditional fetch the register allocator kept a
-        // third and fourth copy of the sets and spilled them inside the k loop.
+        // one batch into one register set.  Lane (kq, i16) serves k-row kb + 4s + kq of step s.  Straight-line code and
+        // NOTHING touches a loaded value here: rows past the end of the longest piece are fetched from its last row and
+        // turned into zeros when the batch is computed (compute()), so the only wait for a set's loads is at its use,
+        // two batches later.  (A select right after the load -- or a conditional fetch -- made the compiler drain every
+        // load at the bottom of the loop: no overlap at all.)
         auto fetch = [&](BV (&R)[LOADS], float (&af)[G][KS], int (&cn)[KS], int kb) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int k = kb + 4 * s + kq;
-                const bool live = k < L;
                 int c;
-                if (RUN) c = c0 + (live ? k : L - 1);
+                if (RUN) c = c0 + (k < L ? k : L - 1);
                 else {
                     c = cn[s];                        // requested two batches ago (clamped the same way)
                     const int k2 = k + 2 * KT;
@@ -718,21 +724,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
                 }
                 const float *rowp = b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colv, c);   // chunk x = + CW*x: an immediate offset
 #pragma unroll
-                for (int x = 0; x < XC; ++x) {
-                    BV v = *reinterpret_cast<const BV *>(rowp + CW * x);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) v[e] = live ? v[e] : 0.f;
-                    R[s * XC + x] = v;
-                }
+                for (int x = 0; x < XC; ++x) R[s * XC + x] = *reinterpret_cast<const BV *>(rowp + CW * x);
             }
 #pragma unroll
             for (int j = 0; j < G; ++j)
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const int k = kb + 4 * s + kq;
-                    const bool live = j < np && k < slen[j];
-                    const float av = a.vals[rowstart[j] + (live ? k : 0)];
-                    af[j][s] = live ? av : 0.f;
+                    af[j][s] = a.vals[rowstart[j] + ((j < np && k < slen[j]) ? k : 0)];
                 }
         };
 #pragma unroll
@@ -742,39 +741,59 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
             cn1[s] = RUN ? 0 : a.col_idx[list0 + (k + KT < L ? k + KT : L - 1)];
         }
         fetch(R0, a0, cn0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         fetch(R1, a1, cn1, KT);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // the MFMAs of one batch: every B operand feeds NA pieces
-        auto compute = [&](auto na_tag, const BV (&R)[LOADS], const float (&af)[G][KS]) {
+        // the MFMAs of one batch: every B operand feeds NA pieces.  Operands of k-rows past the end of a piece become
+        // zeros here (B: past the longest piece; A: past the piece's own end): 0 * 0 terms are exact no-ops.
+        auto compute = [&](auto na_tag, const BV (&R)[LOADS], const float (&af)[G][KS], int kb) {
             constexpr int NA = decltype(na_tag)::value;
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s) {
+                const int k = kb + 4 * s + kq;
+                float av[NA];
+#pragma unroll
+                for (int j = 0; j < NA; ++j) av[j] = (j < np && k < slen[j]) ? af[j][s] : 0.f;
 #pragma unroll
                 for (int x = 0; x < XC; ++x)
 #pragma unroll
-                    for (int e = 0; e < V; ++e)
+                    for (int e = 0; e < V; ++e) {
+                        const float bv = (k < L) ? R[s * XC + x][e] : 0.f;
 #pragma unroll
-                        for (int j = 0; j < NA; ++j)
-                            acc[j][V * x + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], R[s * XC + x][e], acc[j][V * x + e], 0, 0, 0);
+                        for (int j = 0; j < NA; ++j) acc[j][V * x + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[j][V * x + e], 0, 0, 0);
+                    }
+            }
         };
         // Two batches per trip: set 0, refill set 0 for the batch after next, set 1, refill set 1.  A refill past the end
         // of the piece (at most two per item) re-reads the last row and is never used.
+        // sched_barrier pins the ORDER compute(set 0) / refill set 0 / compute(set 1) / refill set 1: the machine scheduler
+        // otherwise sinks both refills to the bottom of the loop with all A-operand loads last, and -- loads return in
+        // order -- the wait for set 0's A operands at the top then waits for every B load: no overlap.
         int kb = 0;
         if (G >= 2 && np >= 2) {
             // both pieces run up to l1, a whole number of batch PAIRS (kShareLenUnit), l1 <= L
             const int l1 = slen[G >= 2 ? 1 : 0];
             for (; kb < l1; kb += 2 * KT) {
-                compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R0, a0);
+                compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R0, a0, kb);
+                __builtin_amdgcn_sched_barrier(0);
                 fetch(R0, a0, cn0, kb + 2 * KT);
-                compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R1, a1, kb + KT);
+                __builtin_amdgcn_sched_barrier(0);
                 fetch(R1, a1, cn1, kb + 3 * KT);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         for (; kb < L; kb += 2 * KT) {
-            compute(std::integral_constant<int, 1>{}, R0, a0);
+            compute(std::integral_constant<int, 1>{}, R0, a0, kb);
+            __builtin_amdgcn_sched_barrier(0);
             fetch(R0, a0, cn0, kb + 2 * KT);
-            compute(std::integral_constant<int, 1>{}, R1, a1);      // past the end: zero operands
+            __builtin_amdgcn_sched_barrier(0);
+            compute(std::integral_constant<int, 1>{}, R1, a1, kb + KT);      // past the end: zero operands
+            __builtin_amdgcn_sched_barrier(0);
             fetch(R1, a1, cn1, kb + 3 * KT);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // Epilogue: register q of the tiles (x, 0..V-1) leaves as V floats per lane, 16 lanes = one 64V-byte row segment,
         // four rows per store instruction.  A tile that a later pass continues stays cacheable; a final one is nt.
