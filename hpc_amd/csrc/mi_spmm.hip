@@ -67,6 +67,9 @@ struct mi_spmm_handle {
     int64_t block_run_min;     // shortest run worth a piece of its own
     BlockItem *d_blk_items;
     int32_t n_blk_items, n_blk_pieces, n_blk_passes, n_blk_shared_items;
+    // preprocess temporaries (grow-only, kept across preprocess calls, released by destroy)
+    Scratch scratch_a, scratch_b;
+    unsigned int *d_col_bad;   // 256 bytes: the column-range flag
     struct { int32_t off, n; } blk_launch[kMaxPieces][3];   // [pass][0: list items, 1: run items of one piece, 2: shared run items]
 };
 
@@ -234,7 +237,8 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     lap(0);
     unsigned int *d_bad = nullptr;
     if (h->nnz > 0) {
-        HIP_TRY(hipMalloc((void **)&d_bad, 256));
+        if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
+        d_bad = h->d_col_bad;
         hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), 0);
         if (e == hipSuccess) {
             const int64_t want = (h->nnz + kBlockThreads * 8 - 1) / (kBlockThreads * 8);
@@ -242,23 +246,22 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
             hipLaunchKernelGGL(csr_check_cols, dim3(grid), dim3(kBlockThreads), 0, 0, h->d_idx, h->nnz, h->num_cols, d_bad);
             e = hipGetLastError();
         }
-        if (e != hipSuccess) { (void)hipFree(d_bad); return (int)e; }
+        if (e != hipSuccess) return (int)e;
     }
     lap(1);
     if (h->block_path && block_path_shape_ok(h->feat) && M >= 16 && h->nnz > 0) {
         const int32_t n_groups = (M + 15) / 16;
-        if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) { if (d_bad) (void)hipFree(d_bad); return MI_SPMM_ENOMEM; }
+        if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
         hipLaunchKernelGGL(detect_row_blocks, dim3((n_groups + 3) / 4), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M, (int32_t)h->nnz,
                            (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
         const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { if (d_bad) (void)hipFree(d_bad); free_plan(h); return (int)e; }
+        if (e != hipSuccess) { free_plan(h); return (int)e; }
     }
     lap(2);
     PlanOut po;
     const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);   // 0 = auto
     const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
-                                  (int32_t)h->long_chunk, &po);
-    if (d_bad) (void)hipFree(d_bad);
+                                  (int32_t)h->long_chunk, &h->scratch_a, &h->scratch_b, &po);
     h->d_chunks = po.d_chunks;
     h->d_long = po.d_long;
     h->d_blk_groups = po.d_blk_groups;
@@ -375,6 +378,9 @@ int mi_spmm_destroy(mi_spmm_handle *h)
     if (!h) return MI_SPMM_OK;
     if (!good(h)) return MI_SPMM_ESTATE;
     free_plan(h);
+    scratch_release(&h->scratch_a);
+    scratch_release(&h->scratch_b);
+    if (h->d_col_bad) (void)hipFree(h->d_col_bad);
     h->magic = 0;
     delete h;
     return MI_SPMM_OK;

@@ -3,6 +3,7 @@
 // on the GPU (preprocess_gpu.hip, default) or by the reference-style host loop (mi_spmm.hip,
 // "gpu_preprocess" = 0, kept as the cross-check).  Internal to libmi_spmm.so.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "plan_types.hpp"
@@ -22,7 +23,15 @@ struct PlanOut {
 // d_blk_flag: per 16-row group, 1 = block path owns it (nullable).  col_bad: device flag written
 // by csr_check_cols earlier on the same (null) stream; read back with the same single copy.
 // mthr: medium threshold, 0 = auto (resolved on the device from the longest row, returned in PlanOut::mthr).
+// A grow-only device arena owned by the handle: preprocess temporaries are carved out of it.
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+int scratch_reserve(Scratch *s, size_t bytes);   // 0 or MI_SPMM_ENOMEM; contents are lost when it grows
+void scratch_release(Scratch *s);
+
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
-                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out);
+                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, Scratch *sa, Scratch *sb, PlanOut *out);
 
 }  // namespace mi

@@ -25,6 +25,11 @@ struct PlanStats {
     int32_t pad[2];
 };
 
+__global__ void init_plan_stats(PlanStats *stats)
+{
+    if (threadIdx.x == 0) *stats = PlanStats{0, 0u, 0, 0, 0, 0, {0, 0}};
+}
+
 // Longest row, ahead of the classification: the auto medium threshold depends on it.
 __global__ __launch_bounds__(kBlockThreads) void row_len_max(const int32_t *__restrict__ row_ptr, int32_t M, PlanStats *stats)
 {
@@ -126,55 +131,95 @@ __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__
 }
 
 namespace {
-struct DevBuf {   // temporary from the stream-ordered pool (hipMalloc/hipFree cost ~0.1 ms each and synchronise)
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFreeAsync(p, 0); }
-    hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 16, 0); }
-    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+// Temporaries are carved out of two grow-only arenas the handle owns (plan.hpp Scratch): no allocation call sits
+// between the kernel launches of a preprocess, and a repeated preprocess allocates nothing.  (Round 2: buffers from
+// hipMallocAsync's pool, allocated while earlier kernels of the same preprocess were in flight, were seen overlapping
+// rocPRIM's scan state in a torch-free process -- the plan statistics came back zeroed now and then.)
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base(reinterpret_cast<char *>(b)) {}
+    template <class T> T *take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T *r = reinterpret_cast<T *>(base + off);
+        off += (n ? n : 1) * sizeof(T);
+        return r;
+    }
 };
 }  // namespace
+
+int scratch_reserve(Scratch *s, size_t bytes)
+{
+    if (s->cap >= bytes && s->p) return 0;
+    if (s->p) (void)hipFree(s->p);
+    s->p = nullptr;
+    s->cap = 0;
+    if (hipMalloc(&s->p, bytes ? bytes : 256) != hipSuccess) return MI_SPMM_ENOMEM;
+    s->cap = bytes ? bytes : 256;
+    return 0;
+}
+
+void scratch_release(Scratch *s)
+{
+    if (s->p) (void)hipFree(s->p);
+    s->p = nullptr;
+    s->cap = 0;
+}
 
 #define PLAN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (e_ == hipErrorOutOfMemory) ? MI_SPMM_ENOMEM : (int)e_; } while (0)
 
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
-                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, PlanOut *out)
+                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, Scratch *sa, Scratch *sb, PlanOut *out)
 {
+    (void)d_col_idx;
     *out = PlanOut();
     out->mthr = (mthr > 0 ? mthr : 64) < thr ? (mthr > 0 ? mthr : 64) : thr;   // replaced by the device's value below
     if (M <= 0) return (nnz == 0) ? MI_SPMM_OK : MI_SPMM_ECSR;
     const size_t n1 = (size_t)M + 1;
-    DevBuf cnt, off, stats, tmp, groups, ngroups;
-    PLAN_TRY(cnt.alloc(3 * n1 * sizeof(int32_t)));
-    PLAN_TRY(off.alloc(3 * n1 * sizeof(int32_t)));
-    PLAN_TRY(stats.alloc(sizeof(PlanStats)));
-    PLAN_TRY(hipMemsetAsync(stats.p, 0, sizeof(PlanStats), 0));
-    int32_t *seg_cnt = cnt.as<int32_t>(), *slot_cnt = seg_cnt + n1, *long_cnt = slot_cnt + n1;
-    int32_t *seg_off = off.as<int32_t>(), *slot_off = seg_off + n1, *long_off = slot_off + n1;
-    const unsigned grid = (unsigned)((n1 + kBlockThreads - 1) / kBlockThreads);
-    hipLaunchKernelGGL(row_len_max, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats.as<PlanStats>());
-    hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
-                       (int32_t)(nnz / M), thr, clen, seg_cnt, slot_cnt, long_cnt, stats.as<PlanStats>());
-    PLAN_TRY(hipGetLastError());
-    size_t tb = 0, tb2 = 0;
-    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, seg_cnt, seg_off, (int)n1));
     const int n_groups_all = (M + 15) / 16;
-    if (d_blk_flag) {
+    // sizes first (the queries touch no memory), then ONE reservation, then the launches
+    size_t tb = 0, tb2 = 0;
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (int32_t *)nullptr, (int32_t *)nullptr, (int)n1));
+    if (d_blk_flag)
         PLAN_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb2, hipcub::CountingInputIterator<int32_t>(0), d_blk_flag,
                                                (int32_t *)nullptr, (int32_t *)nullptr, n_groups_all));
-        PLAN_TRY(groups.alloc((size_t)n_groups_all * sizeof(int32_t)));
+    int32_t *cnt = nullptr, *off = nullptr, *groups = nullptr;
+    PlanStats *stats = nullptr;
+    char *tmp = nullptr;
+    auto layout_a = [&](Carver &c) {
+        cnt = c.take<int32_t>(3 * n1);
+        off = c.take<int32_t>(3 * n1);
+        stats = c.take<PlanStats>(1);
+        tmp = c.take<char>(tb > tb2 ? tb : tb2);
+        groups = c.take<int32_t>(d_blk_flag ? (size_t)n_groups_all : 1);
+    };
+    {
+        Carver dry(nullptr);
+        layout_a(dry);
+        const int rc = scratch_reserve(sa, dry.off + 256);
+        if (rc != 0) return rc;
+        Carver real(sa->p);
+        layout_a(real);
     }
-    PLAN_TRY(tmp.alloc(tb > tb2 ? tb : tb2));
+    hipLaunchKernelGGL(init_plan_stats, dim3(1), dim3(64), 0, 0, stats);   // same queue as the kernels that fill it
+    int32_t *seg_cnt = cnt, *slot_cnt = seg_cnt + n1, *long_cnt = slot_cnt + n1;
+    int32_t *seg_off = off, *slot_off = seg_off + n1, *long_off = slot_off + n1;
+    const unsigned grid = (unsigned)((n1 + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL(row_len_max, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats);
+    hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
+                       (int32_t)(nnz / M), thr, clen, seg_cnt, slot_cnt, long_cnt, stats);
+    PLAN_TRY(hipGetLastError());
     size_t t = tb;
-    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, seg_cnt, seg_off, (int)n1));
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, t, seg_cnt, seg_off, (int)n1));
     t = tb;
-    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, slot_cnt, slot_off, (int)n1));
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, t, slot_cnt, slot_off, (int)n1));
     t = tb;
-    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, long_cnt, long_off, (int)n1));
+    PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, t, long_cnt, long_off, (int)n1));
     if (d_blk_flag) {
         t = tb2;
-        PLAN_TRY(hipcub::DeviceSelect::Flagged(tmp.p, t, hipcub::CountingInputIterator<int32_t>(0), d_blk_flag,
-                                               groups.as<int32_t>(), &stats.as<PlanStats>()->n_groups_selected,
-                                               n_groups_all));
+        PLAN_TRY(hipcub::DeviceSelect::Flagged(tmp, t, hipcub::CountingInputIterator<int32_t>(0), d_blk_flag, groups,
+                                               &stats->n_groups_selected, n_groups_all));
     }
     // the one copy back: totals (element M of each scan), stats, and the column-check flag
     struct { int32_t n_chunks, n_slots, n_long; PlanStats st; unsigned int col_bad; } host;
@@ -182,14 +227,15 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     PLAN_TRY(hipMemcpyAsync(&host.n_chunks, seg_off + M, sizeof(int32_t), hipMemcpyDeviceToHost, 0));
     PLAN_TRY(hipMemcpyAsync(&host.n_slots, slot_off + M, sizeof(int32_t), hipMemcpyDeviceToHost, 0));
     PLAN_TRY(hipMemcpyAsync(&host.n_long, long_off + M, sizeof(int32_t), hipMemcpyDeviceToHost, 0));
-    PLAN_TRY(hipMemcpyAsync(&host.st, stats.p, sizeof(PlanStats), hipMemcpyDeviceToHost, 0));
+    PLAN_TRY(hipMemcpyAsync(&host.st, stats, sizeof(PlanStats), hipMemcpyDeviceToHost, 0));
     if (d_col_bad) PLAN_TRY(hipMemcpyAsync(&host.col_bad, d_col_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, 0));
     PLAN_TRY(hipStreamSynchronize(0));
     // data.cu:40-45 asserts ptr[num_v] == num_e; monotone rows and in-range columns keep the kernels in bounds
     if (host.st.bad || host.col_bad || (int64_t)host.st.ptrM != nnz || host.st.ptr0 < 0) {
         if (getenv("MI_SPMM_DEBUG"))
-            fprintf(stderr, "mi_spmm: CSR rejected: negative-length/ptr0 bits %u, column out of range %u, row_ptr[0] = %d, row_ptr[M] = %d, nnz = %lld\n",
-                    host.st.bad, host.col_bad, host.st.ptr0, host.st.ptrM, (long long)nnz);
+            fprintf(stderr, "mi_spmm: CSR rejected: negative-length/ptr0 bits %u, column out of range %u, row_ptr[0] = %d, row_ptr[M] = %d, nnz = %lld "
+                            "(M = %d, longest row %d, medium threshold %d, segments %d)\n",
+                    host.st.bad, host.col_bad, host.st.ptr0, host.st.ptrM, (long long)nnz, M, host.st.max_len, host.st.mthr, host.n_chunks);
         return MI_SPMM_ECSR;
     }
     out->max_len = host.st.max_len;
@@ -203,33 +249,41 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
         // the qualifying groups in row order; build_block_items (mi_spmm.hip) cuts them into pieces and orders those
         const int ng = out->n_blk_groups;
         PLAN_TRY(hipMalloc((void **)&out->d_blk_groups, (size_t)ng * sizeof(int32_t)));
-        PLAN_TRY(hipMemcpyAsync(out->d_blk_groups, groups.p, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToDevice, 0));
-        PLAN_TRY(hipStreamSynchronize(0));
+        PLAN_TRY(hipMemcpyAsync(out->d_blk_groups, groups, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToDevice, 0));
     }
     if (host.n_chunks > 0) {
-        DevBuf unsorted, keys_in, keys_out, tmp2;
         const size_t n = (size_t)host.n_chunks;
-        PLAN_TRY(unsorted.alloc(n * sizeof(Chunk)));
-        PLAN_TRY(keys_in.alloc(n * sizeof(uint32_t)));
-        PLAN_TRY(keys_out.alloc(n * sizeof(uint32_t)));
+        int end_bit = 1;
+        while (end_bit < 32 && (host.st.max_len >> end_bit)) ++end_bit;
+        size_t sbytes = 0;
+        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sbytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (Chunk *)nullptr,
+                                                              (Chunk *)nullptr, (int)n, 0, end_bit));
+        Chunk *unsorted = nullptr;
+        uint32_t *keys_in = nullptr, *keys_out = nullptr;
+        char *tmp2 = nullptr;
+        auto layout_b = [&](Carver &c) {
+            unsorted = c.take<Chunk>(n);
+            keys_in = c.take<uint32_t>(n);
+            keys_out = c.take<uint32_t>(n);
+            tmp2 = c.take<char>(sbytes);
+        };
+        {
+            Carver dry(nullptr);
+            layout_b(dry);
+            const int rc = scratch_reserve(sb, dry.off + 256);
+            if (rc != 0) return rc;
+            Carver real(sb->p);
+            layout_b(real);
+        }
         PLAN_TRY(hipMalloc((void **)&out->d_chunks, n * sizeof(Chunk)));
         PLAN_TRY(hipMalloc((void **)&out->d_long, (host.n_long > 0 ? (size_t)host.n_long : 1) * sizeof(LongRow)));
         hipLaunchKernelGGL(emit_segments, dim3((unsigned)(((size_t)M + kBlockThreads - 1) / kBlockThreads)),
                            dim3(kBlockThreads), 0, 0, d_row_ptr, M, thr, clen, seg_cnt, seg_off, slot_off, long_off,
-                           unsorted.as<Chunk>(), keys_in.as<uint32_t>(), out->d_long);
+                           unsorted, keys_in, out->d_long);
         PLAN_TRY(hipGetLastError());
-        int end_bit = 1;
-        while (end_bit < 32 && (host.st.max_len >> end_bit)) ++end_bit;
-        size_t sb = 0;
-        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(),
-                                                              unsorted.as<Chunk>(), out->d_chunks, (int)n, 0, end_bit));
-        PLAN_TRY(tmp2.alloc(sb));
-        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2.p, sb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(),
-                                                              unsorted.as<Chunk>(), out->d_chunks, (int)n, 0, end_bit));
-        PLAN_TRY(hipStreamSynchronize(0));   // temporaries die at scope exit
-    } else {
-        PLAN_TRY(hipStreamSynchronize(0));
+        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
     }
+    PLAN_TRY(hipStreamSynchronize(0));
     return MI_SPMM_OK;
 }
 

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condense the passes of scripts/prof.sh into profiles/<tag>_profile.json (+ the verbatim kernel_stats.csv).
+
+    python scripts/summarize_prof2.py <tag> <steps> <kernel-substring> [launches-before-steps]
+
+Reads gpurun_out/<tag>_{stats,fetch,write,tcc,sq}/ (rocprofv3 --output-format csv).  For every kernel whose name
+contains the substring: calls, average duration, per-launch counter means; and PER STEP (= one run() of the
+operator, which may be several launches of several kernels): time, traffic (FETCH_SIZE/WRITE_SIZE are KiB;
+FETCH_SIZE doubled -- gfx950 tallies 128-byte requests of 16-byte-per-lane reads at 64 bytes,
+MI355X_MICROARCH.md, HBM section; the counters sit on the L2's memory side, so Infinity-Cache hits are
+included), L2 hit rate, MFMA busy share.  `steps` = timed + warm-up launches of the whole step in the profiled
+command (every launch of a matching kernel is assumed to belong to a step).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(d, sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    tag, steps, sub = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    base = os.path.join(ROOT, "gpurun_out", tag)
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    summary = {"tag": tag, "kernel_filter": sub, "steps": steps, "kernels": {}}
+    ks = glob.glob(os.path.join(base + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+        for r in csv.DictReader(open(ks[0])):
+            if sub in r["Name"]:
+                summary["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                                 "max_ns": float(r["MaxNs"]), "pct_of_gpu_time": float(r["Percentage"])}
+    tot = collections.defaultdict(float)
+    for p in ("fetch", "write", "tcc", "sq"):
+        for name, cs in counters(base + "_" + p, sub).items():
+            k = summary["kernels"].setdefault(name, {})
+            for c, v in cs.items():
+                k.setdefault("counters_per_launch", {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
+                tot[c] += sum(v) / steps          # all launches of all matching kernels, per step
+    step = {"ns": sum(k.get("avg_ns", 0.0) * k.get("calls", 0) for k in summary["kernels"].values()) / steps,
+            "launches": sum(k.get("calls", 0) for k in summary["kernels"].values()) / steps}
+    if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+        step["fetch_bytes_x2"] = 2.0 * tot["FETCH_SIZE"] * 1024.0
+        step["write_bytes"] = tot["WRITE_SIZE"] * 1024.0
+        step["traffic_bytes"] = step["fetch_bytes_x2"] + step["write_bytes"]
+    if "TCC_HIT_sum" in tot:
+        step["l2_hit_rate"] = tot["TCC_HIT_sum"] / max(1.0, tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"])
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in tot:
+        step["mfma_mops_f32"] = tot.get("SQ_INSTS_VALU_MFMA_MOPS_F32")
+        # busy cycles are summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs
+        step["mfma_busy_cycles_per_simd"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
+        if tot.get("GRBM_GUI_ACTIVE"):
+            step["gui_active_cycles"] = tot["GRBM_GUI_ACTIVE"] / 8.0
+            step["mfma_busy_frac"] = step["mfma_busy_cycles_per_simd"] / step["gui_active_cycles"]
+    summary["per_step"] = step
+    json.dump(summary, open(os.path.join(out, f"{tag}_profile.json"), "w"), indent=1)
+    print(json.dumps(summary["per_step"], indent=1))
+    for n, k in summary["kernels"].items():
+        print(n[:100], k.get("calls"), k.get("avg_ns"))
+
+
+if __name__ == "__main__":
+    main()
