@@ -52,6 +52,7 @@ struct mi_spmm_handle {
     int64_t ldp;
     size_t ws_bytes;
     int32_t max_row_nnz;
+    int32_t local_pct;   // column locality sample (percent); -1 = not measured (host plan builder)
     double preprocess_us;
     double phase_us[5];  // d2h row_ptr + validate, column check, block detection, host segment table, upload
     int32_t last_lpr, last_v, last_launches, last_wide;
@@ -98,6 +99,7 @@ static void free_plan(mi_spmm_handle *h)
     h->d_long = nullptr;
     h->d_partials = nullptr;
     h->n_chunks = h->n_long = h->n_medium = h->n_slots = 0;
+    h->local_pct = -1;
     h->ws_bytes = 0;
     h->prepared = false;
 }
@@ -260,7 +262,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     lap(2);
     PlanOut po;
     const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);   // 0 = auto
-    const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
+    const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
                                   (int32_t)h->long_chunk, &h->scratch_a, &h->scratch_b, &po);
     h->d_chunks = po.d_chunks;
     h->d_long = po.d_long;
@@ -273,6 +275,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     h->n_blk_groups = po.n_blk_groups;
     h->max_row_nnz = po.max_len;
     h->medium_res = po.mthr;
+    h->local_pct = po.local_pct;
     if (h->n_blk_groups == 0 && h->d_blk_flag) { (void)hipFree(h->d_blk_flag); h->d_blk_flag = nullptr; }
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)h->n_medium;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
@@ -444,6 +447,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_chunks") *value = h->n_chunks;
     else if (k == "workspace_bytes") *value = (int64_t)h->ws_bytes;
     else if (k == "max_row_nnz") *value = h->max_row_nnz;
+    else if (k == "column_locality_pct") *value = h->local_pct;
     else if (k == "n_launches") *value = h->last_launches;
     else if (k == "lanes_per_row") *value = h->last_lpr;
     else if (k == "vector_width") *value = h->last_v;
@@ -764,11 +768,22 @@ void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 g
     else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s); else launch_block_items_g<1, false, false>(slab, a, grid, s); }
 }
 
-// auto: see profiles/r02_wide_n_tiles.txt
+// Column-tile width of the rows / segment kernels when the caller leaves it to us (profiles/r02_wide_n_tiles.txt):
+//   columns near the row's own position (banded / mesh / community structure): whole-wave tiles -- neighbouring rows
+//     share B rows through L2 and a narrower tile only re-reads A (banded N=256: 1.75 ms at 256, 1.88 at 128, 2.15 at 64);
+//   otherwise, N >= 256: 64-column tiles -- the tiles are swept one after the other, so a sweep's B working set is
+//     K x 64 x 4 bytes (256 MiB at K = 2^20: the Infinity Cache's size) instead of 1 GiB (uniform N=1024: 20.3 -> 19.4 ms,
+//     N=256: 5.44 -> 4.79; R-MAT N=512: 10.3 -> 8.3; dense-ish: +6 %);
+//   N < 256 with hub rows (longest row > 64 x mean: R-MAT-like column reuse): 64 as well (R-MAT N=128: 2.09 -> 1.81 ms);
+//   else the whole row (uniform N=128: 2.40 at 128, 2.42 at 64, 2.57 at 32).
 int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
 {
+    (void)ldb;
     if (h->tile_cols > 0) return (int)h->tile_cols;
-    (void)N; (void)ldb;
+    if (h->local_pct < 0 || h->local_pct >= 50) return 256;
+    if (N >= 256) return 64;
+    const int64_t mean = h->num_v > 0 ? h->nnz / h->num_v : 0;
+    if (N >= 128 && (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1)) return 64;
     return 256;
 }
 

@@ -34,6 +34,7 @@ struct mi_spmm_dist {
     int32_t M = 0, n_loc = 0, rank = 0, world = 1, n_panels = 1;
     int64_t N_total = 0;
     int exchange = kAllGather;
+    bool rehearse = false;                     // run the exchange machinery even at world == 1 (one-GPU rehearsal)
     std::vector<std::pair<int32_t, int32_t>> panels;
     int32_t rows_max = 0;
     // streams / events (created on first use, on the device current at that time)
@@ -150,7 +151,7 @@ int ensure_token(mi_spmm_dist *d)
 // every rank has finished everything it enqueued on its exchange stream before this point
 int device_barrier(mi_spmm_dist *d, hipStream_t s)
 {
-    if (!d->comm || d->world == 1) return 0;
+    if (!d->comm) return 0;
     MI_TRY(ensure_token(d));
     NCCL_TRY(ncclAllReduce(d->d_token, d->d_token, 1, ncclFloat, ncclSum, d->comm, s));
     return 0;
@@ -169,7 +170,6 @@ int exchange_panel(mi_spmm_dist *d, float *stage, int32_t rows, hipStream_t s)
 {
     const size_t blk = (size_t)rows * (size_t)d->n_loc;
     float *own = stage + (size_t)d->rank * blk;
-    if (d->world == 1) return 0;
     if (d->exchange == kAllGather) {
         NCCL_TRY(ncclAllGather(own, stage, blk, ncclFloat, d->comm, s));   // in place: sendbuff == recvbuff + rank * count
         return 0;
@@ -192,7 +192,7 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
     if (d->M == 0 || d->n_loc == 0) return 0;
     if (!d_C_full || (do_compute && !d_B_loc)) return MI_SPMM_EINVAL;
     const int64_t n_loc = d->n_loc, NT = d->N_total;
-    if (d->world == 1) {   // nothing to exchange: the local block IS C
+    if (d->world == 1 && !d->rehearse) {   // nothing to exchange: the local block IS C
         if (do_compute) return mi_spmm_run_rows(d->h, d_B_loc, n_loc, d_C_full, NT, 0, d->M, (void *)main);
         return 0;
     }
@@ -385,6 +385,7 @@ int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
     if (!good(d) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
     if (k == "exchange") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; d->exchange = (int)v; }
+    else if (k == "rehearse") d->rehearse = v != 0;
     else if (k == "n_panels") {
         if (v < 1 || v > (1 << 20)) return MI_SPMM_EINVAL;
         (void)hipDeviceSynchronize();   // staging buffers of a step in flight

@@ -17,6 +17,7 @@ struct PlanOut {
     int32_t n_chunks = 0, n_long = 0, n_slots = 0, n_medium = 0, n_blk_groups = 0;
     int32_t max_len = 0;
     int32_t mthr = 0;               // resolved medium threshold (the rows kernel skips rows above it)
+    int32_t local_pct = 0;          // sampled nonzeros within a window of their row's own position, percent (column-tile rule)
 };
 
 // Returns 0, a negative MI_SPMM_E* code (malformed CSR, out of memory) or a positive hipError_t.
@@ -31,7 +32,7 @@ struct Scratch {
 int scratch_reserve(Scratch *s, size_t bytes);   // 0 or MI_SPMM_ENOMEM; contents are lost when it grows
 void scratch_release(Scratch *s);
 
-int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
+int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, const uint8_t *d_blk_flag,
                    const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, Scratch *sa, Scratch *sb, PlanOut *out);
 
 }  // namespace mi

@@ -22,12 +22,42 @@ struct PlanStats {
     int32_t ptr0, ptrM;
     int32_t n_groups_selected;
     int32_t mthr;      // resolved medium threshold (auto rule below, or the caller's value), already capped by thr
-    int32_t pad[2];
+    int32_t near, sampled;   // column locality sample: nonzeros of sampled rows whose column lies near the row's own position
 };
 
 __global__ void init_plan_stats(PlanStats *stats)
 {
-    if (threadIdx.x == 0) *stats = PlanStats{0, 0u, 0, 0, 0, 0, {0, 0}};
+    if (threadIdx.x == 0) *stats = PlanStats{0, 0u, 0, 0, 0, 0, 0, 0};
+}
+
+// Column locality of a row sample: how many nonzeros sit within `window` columns of their row's own position
+// (row r of M <-> column r*K/M).  Mesh / community / banded structures score ~1, random columns ~2*window/K.
+// Only the column-tile width of the rows kernel depends on it (scheduling, never arithmetic).
+__global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
+                                                                int32_t M, int32_t K, int64_t nnz, int32_t n_samples, int32_t window, PlanStats *stats)
+{
+    const int i = (int)(blockIdx.x * (unsigned)kBlockThreads + threadIdx.x);
+    int near = 0, tot = 0;
+    if (i < n_samples) {
+        const int r = (int)((int64_t)i * M / n_samples);
+        const int beg = row_ptr[r], end = row_ptr[r + 1];
+        const int64_t home = (int64_t)r * K / (M > 0 ? M : 1);
+        if (beg >= 0 && end <= nnz && end - beg <= 4096) {     // runs before row_ptr has been validated; hubs say nothing about locality
+            for (int k = beg; k < end; ++k) {
+                const int64_t d = (int64_t)col_idx[k] - home;
+                near += (d <= window && d >= -(int64_t)window) ? 1 : 0;
+            }
+            tot = end - beg;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        near += __shfl_down(near, off, 64);
+        tot += __shfl_down(tot, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && tot > 0) {
+        atomicAdd(&stats->near, near);
+        atomicAdd(&stats->sampled, tot);
+    }
 }
 
 // Longest row, ahead of the classification: the auto medium threshold depends on it.
@@ -169,10 +199,9 @@ void scratch_release(Scratch *s)
 
 #define PLAN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (e_ == hipErrorOutOfMemory) ? MI_SPMM_ENOMEM : (int)e_; } while (0)
 
-int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int64_t nnz, const uint8_t *d_blk_flag,
+int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, const uint8_t *d_blk_flag,
                    const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, Scratch *sa, Scratch *sb, PlanOut *out)
 {
-    (void)d_col_idx;
     *out = PlanOut();
     out->mthr = (mthr > 0 ? mthr : 64) < thr ? (mthr > 0 ? mthr : 64) : thr;   // replaced by the device's value below
     if (M <= 0) return (nnz == 0) ? MI_SPMM_OK : MI_SPMM_ECSR;
@@ -207,6 +236,12 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     int32_t *seg_off = off, *slot_off = seg_off + n1, *long_off = slot_off + n1;
     const unsigned grid = (unsigned)((n1 + kBlockThreads - 1) / kBlockThreads);
     hipLaunchKernelGGL(row_len_max, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats);
+    if (nnz > 0 && K > 0) {
+        const int n_samples = M < 8192 ? M : 8192;
+        const int window = K / 64 > 4096 ? K / 64 : 4096;
+        hipLaunchKernelGGL(sample_locality, dim3((unsigned)((n_samples + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
+                           d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
+    }
     hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
                        (int32_t)(nnz / M), thr, clen, seg_cnt, slot_cnt, long_cnt, stats);
     PLAN_TRY(hipGetLastError());
@@ -240,6 +275,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     }
     out->max_len = host.st.max_len;
     out->mthr = host.st.mthr;
+    out->local_pct = host.st.sampled > 0 ? (int32_t)(100.0 * host.st.near / host.st.sampled) : 0;
     out->n_chunks = host.n_chunks;
     out->n_slots = host.n_slots;
     out->n_long = host.n_long;

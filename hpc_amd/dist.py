@@ -230,3 +230,167 @@ class ColumnShardedSpMM:
                 unpacked[p & 1] = done
         main.wait_stream(comm)
         main.wait_stream(post)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The product path on GPUs: the same step behind the C ABI of include/mi_spmm_dist.h
+# (hpc_amd/libmi_spmm_dist.so: streams, RCCL calls and strided peer copies in C++, no torch in its
+# signatures).  torch.distributed is only the bootstrap here -- it carries the 128-byte RCCL unique id
+# and the HIP IPC handles between the ranks, as MPI_Bcast / MPI_Allgather would in a C++ host.
+# ColumnShardedSpMM above stays as the device-agnostic statement of the schedule that the world_size-2
+# gloo tests drive on CPU tensors.
+# ---------------------------------------------------------------------------------------------------
+import ctypes as _C
+import os as _os
+
+_DIST_LIB = None
+_DIST_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmi_spmm_dist.so")
+_P = _C.c_void_p
+_DIST_SIGNATURES = {
+    "mi_spmm_dist_create": (_C.c_int, [_C.POINTER(_P), _P, _C.c_int32, _C.c_int32, _C.c_int32, _C.c_int32, _C.c_int32]),
+    "mi_spmm_dist_destroy": (_C.c_int, [_P]),
+    "mi_spmm_dist_unique_id": (_C.c_int, [_P]),
+    "mi_spmm_dist_comm_init": (_C.c_int, [_P, _P]),
+    "mi_spmm_dist_set_comm": (_C.c_int, [_P, _P]),
+    "mi_spmm_dist_export_c": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_set_peers": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_set_option": (_C.c_int, [_P, _C.c_char_p, _C.c_int64]),
+    "mi_spmm_dist_get_option": (_C.c_int, [_P, _C.c_char_p, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_run": (_C.c_int, [_P, _P, _P, _P]),
+    "mi_spmm_dist_run_compute_only": (_C.c_int, [_P, _P, _P, _P]),
+    "mi_spmm_dist_run_exchange_only": (_C.c_int, [_P, _P, _P]),
+    "mi_spmm_dist_strerror": (_C.c_char_p, [_C.c_int]),
+}
+UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
+EXCHANGE_CODES = {"allgather": 0, "direct": 1, "peer2d": 2}
+
+
+class MiSpmmDistError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = int(code)
+        msg = load_dist().mi_spmm_dist_strerror(self.code)
+        super().__init__(f"{where}: [{self.code}] {msg.decode() if msg else 'unknown'}")
+
+
+def load_dist():
+    """libmi_spmm_dist.so, every symbol of include/mi_spmm_dist.h bound; raises when it is not built (no fallback)."""
+    global _DIST_LIB
+    if _DIST_LIB is not None:
+        return _DIST_LIB
+    if not _os.path.exists(_DIST_PATH):
+        raise RuntimeError(f"{_DIST_PATH} not found: build it with `make -C hpc_amd/csrc` (or __graft_entry__.build())")
+    from . import _lib
+
+    _lib.load()                                   # libmi_spmm.so first (the dist library links it)
+    lib = _C.CDLL(_DIST_PATH)
+    for name, (res, args) in _DIST_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _DIST_LIB = lib
+    return lib
+
+
+def _dcheck(code, where):
+    if code != 0:
+        raise MiSpmmDistError(code, where)
+
+
+class NativeColumnShardedSpMM:
+    """The column-sharded step through the C ABI.  op: a PREPROCESSED hpc_amd.SpMMOpt for this rank's n_loc columns.
+
+        sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=8, exchange="allgather")
+        sh.init_comm()                    # collective over torch.distributed (any backend): RCCL communicator of our own
+        sh.set_peers(C_full)              # collective, only for exchange="peer2d": HIP IPC handles of every rank's C_full
+        sh.run(B_loc, C_full)             # asynchronous on torch's current stream
+    """
+
+    def __init__(self, op, layout: ShardLayout, n_panels: int = 8, exchange: str = "allgather", group=None, rehearse: bool = False):
+        self._lib = load_dist()
+        self.op = op
+        self.layout = layout
+        self.group = group
+        self._d = _P(None)
+        _dcheck(self._lib.mi_spmm_dist_create(_C.byref(self._d), op._h, layout.M, layout.n_loc, layout.rank, layout.world, int(n_panels)),
+                "mi_spmm_dist_create")
+        self.set_exchange(exchange)
+        if rehearse:
+            self.set_option("rehearse", 1)
+        self.has_comm = False
+
+    def __del__(self):
+        d = getattr(self, "_d", None)
+        if d is not None and d.value:
+            self._lib.mi_spmm_dist_destroy(d)
+            self._d = _P(None)
+
+    def set_option(self, key, value):
+        _dcheck(self._lib.mi_spmm_dist_set_option(self._d, key.encode(), int(value)), f"mi_spmm_dist_set_option({key})")
+
+    def get_option(self, key):
+        v = _C.c_int64(0)
+        _dcheck(self._lib.mi_spmm_dist_get_option(self._d, key.encode(), _C.byref(v)), f"mi_spmm_dist_get_option({key})")
+        return v.value
+
+    def set_exchange(self, name):
+        if name not in EXCHANGE_CODES:
+            raise ValueError(f"exchange must be one of {tuple(EXCHANGE_CODES)}")
+        self.exchange = name
+        self.set_option("exchange", EXCHANGE_CODES[name])
+
+    def init_comm(self):
+        """Collective.  Rank 0 draws the RCCL unique id, torch.distributed broadcasts its 128 bytes, every rank joins."""
+        import torch.distributed as dist
+
+        buf = (_C.c_char * UNIQUE_ID_BYTES)()
+        if self.layout.world > 1:
+            box = [None]
+            if self.layout.rank == 0:
+                _dcheck(self._lib.mi_spmm_dist_unique_id(buf), "mi_spmm_dist_unique_id")
+                box[0] = bytes(buf)
+            src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+            dist.broadcast_object_list(box, src=src, group=self.group)
+            _C.memmove(buf, box[0], UNIQUE_ID_BYTES)
+        else:
+            _dcheck(self._lib.mi_spmm_dist_unique_id(buf), "mi_spmm_dist_unique_id")
+        _dcheck(self._lib.mi_spmm_dist_comm_init(self._d, buf), "mi_spmm_dist_comm_init")
+        self.has_comm = True
+
+    def set_peers(self, C_full):
+        """Collective (exchange="peer2d").  Every rank exports its C_full; the handle table goes to the library."""
+        import torch.distributed as dist
+
+        L = self.layout
+        h = (_C.c_char * IPC_HANDLE_BYTES)()
+        off = _C.c_int64(0)
+        _dcheck(self._lib.mi_spmm_dist_export_c(self._d, _P(C_full.data_ptr()), h, _C.byref(off)), "mi_spmm_dist_export_c")
+        mine = (bytes(h), int(off.value))
+        if L.world > 1:
+            table = [None] * L.world
+            dist.all_gather_object(table, mine, group=self.group)
+        else:
+            table = [mine]
+        handles = (_C.c_char * (IPC_HANDLE_BYTES * L.world))()
+        offsets = (_C.c_int64 * L.world)()
+        for q, (hb, ob) in enumerate(table):
+            _C.memmove(_C.addressof(handles) + q * IPC_HANDLE_BYTES, hb, IPC_HANDLE_BYTES)
+            offsets[q] = ob
+        _dcheck(self._lib.mi_spmm_dist_set_peers(self._d, _P(C_full.data_ptr()), handles, offsets), "mi_spmm_dist_set_peers")
+        self._peers_of = C_full           # keep the exported tensor alive
+
+    @staticmethod
+    def _stream():
+        import torch
+
+        return _P(torch.cuda.current_stream().cuda_stream)
+
+    def run(self, B_loc, C_full):
+        _dcheck(self._lib.mi_spmm_dist_run(self._d, _P(B_loc.data_ptr()), _P(C_full.data_ptr()), self._stream()), "mi_spmm_dist_run")
+
+    def run_compute_only(self, B_loc, C_full):
+        _dcheck(self._lib.mi_spmm_dist_run_compute_only(self._d, _P(B_loc.data_ptr()), _P(C_full.data_ptr()), self._stream()),
+                "mi_spmm_dist_run_compute_only")
+
+    def run_exchange_only(self, C_full):
+        _dcheck(self._lib.mi_spmm_dist_run_exchange_only(self._d, _P(C_full.data_ptr()), self._stream()), "mi_spmm_dist_run_exchange_only")

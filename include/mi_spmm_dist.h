@@ -68,7 +68,8 @@ int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm);
 int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out);
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
-/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d), "n_panels"; read-only: "world", "rank", "has_comm",
+/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d), "n_panels", "rehearse" (1: run the staging / collective /
+ * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path); read-only: "world", "rank", "has_comm",
  * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step" */
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);
 int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *value);

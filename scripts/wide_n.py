@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--one", type=int, nargs=2, default=None)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--structure", default="uniform", help="uniform (C1's CSR) | powerlaw | rmat | banded | denseish")
     args = ap.parse_args()
     import torch
     from hpc_amd import CSR, SpMMOpt, synth
@@ -34,7 +35,19 @@ def main():
 
     dev = torch.device("cuda:0")
     M = 1 << 20
-    ptr, idx = synth.csr_uniform(M, 16, 48)
+    if args.structure == "uniform":
+        ptr, idx = synth.csr_uniform(M, 16, 48)
+    elif args.structure == "powerlaw":
+        ptr, idx = synth.csr_powerlaw(M, 32.0, 4096)
+    elif args.structure == "rmat":
+        ptr, idx = synth.csr_rmat(20, 32)
+    elif args.structure == "banded":
+        ptr, idx = synth.csr_banded(M)
+    elif args.structure == "denseish":
+        M = 1 << 18
+        ptr, idx = synth.csr_uniform(M, 300, 700)
+    else:
+        raise SystemExit("unknown structure")
     vals = synth.make_values(idx.size)
     nnz = int(idx.size)
     d_ptr, d_idx, d_val = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals))
@@ -84,10 +97,10 @@ def main():
         model = synth.bytes_model(M, M, N, nnz)
         for t in ops:
             ms = float(np.median(res[t]))
-            print(json.dumps({"N": N, "tile_cols": t, "lanes_per_row": ops[t].get_option("lanes_per_row"), "ms_median": round(ms, 4),
+            print(json.dumps({"structure": args.structure, "N": N, "tile_cols": t, "lanes_per_row": ops[t].get_option("lanes_per_row"), "ms_median": round(ms, 4),
                               "ms_all": [round(x, 4) for x in res[t]], "GBs_alg": round(model["bytes_alg"] / ms / 1e6, 1),
                               "frac_8TBs": round(model["bytes_alg"] / ms / 1e6 / 8000, 4)}), flush=True)
-        if N == 1024:
+        if N == 1024 and args.structure == "uniform":
             # one 128-column strip of the wide B (row pitch 1024): N = 128's bytes, N = 1024's address footprint
             op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), 128)
             op.preprocess(d_B, d_C)

@@ -100,3 +100,46 @@ def test_no_cpu_fallback_in_the_operator():
         _lib.LIB_PATH = real
         _lib._lib = None
         _lib.load()
+
+
+# ---- the column-sharded step's own library (include/mi_spmm_dist.h -> hpc_amd/libmi_spmm_dist.so) ----
+def _declared_dist():
+    text = open(os.path.join(ROOT, "include", "mi_spmm_dist.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_spmm_dist_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_dist_library_exports_every_declared_symbol_and_binding_covers_header():
+    from hpc_amd import dist
+
+    names = _declared_dist()
+    for must in ("mi_spmm_dist_create", "mi_spmm_dist_run", "mi_spmm_dist_comm_init", "mi_spmm_dist_set_peers", "mi_spmm_dist_destroy"):
+        assert must in names
+    lib = ctypes.CDLL(dist._DIST_PATH)
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/mi_spmm_dist.h but not exported"
+    assert sorted(dist._DIST_SIGNATURES) == names
+    # the operator library itself stays free of any communication dependency
+    import subprocess
+    from hpc_amd import _lib
+
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "rocsparse" not in needed
+    assert "rccl" in subprocess.run(["readelf", "-d", dist._DIST_PATH], capture_output=True, text=True).stdout
+
+
+def test_dist_argument_checks_without_a_gpu():
+    from hpc_amd import _lib, dist
+
+    lib = dist.load_dist()
+    d = ctypes.c_void_p(None)
+    assert lib.mi_spmm_dist_create(ctypes.byref(d), None, 4, 4, 0, 1, 1) == -1                 # NULL operator
+    dummy = (ctypes.c_int32 * 5)()
+    h = ctypes.c_void_p(None)
+    assert _lib.load().mi_spmm_create(ctypes.byref(h), dummy, None, None, 4, 4, 0, 8) == 0
+    assert lib.mi_spmm_dist_create(ctypes.byref(d), h, 4, 8, 0, 1, 1) == -3                    # operator not preprocessed
+    assert lib.mi_spmm_dist_create(ctypes.byref(d), h, 4, 8, 2, 2, 1) == -1                    # rank >= world
+    assert lib.mi_spmm_dist_destroy(None) == 0
+    assert b"NCCL" in lib.mi_spmm_dist_strerror(-1003) or b"internal" in lib.mi_spmm_dist_strerror(-1003)
+    assert b"invalid argument" in lib.mi_spmm_dist_strerror(-1)
+    _lib.load().mi_spmm_destroy(h)

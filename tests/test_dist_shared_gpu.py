@@ -89,3 +89,83 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_gpu_result(world, M, n_loc, 
         assert streams, "the GPU run must use the three-stream pipeline"
         assert nans == 0, f"rank {rank}: {nans} elements of C never written"
         assert same, f"rank {rank}: gathered C differs from the single-operator C"
+
+
+# ---- the same check through the C ABI of include/mi_spmm_dist.h (hpc_amd/libmi_spmm_dist.so) ----
+def _native_worker(rank, world, port, M, n_loc, n_panels, kind, q):
+    """exchange "peer2d": every rank maps the other ranks' C_full through HIP IPC (here: other processes on the same
+    GPU) and pushes its column block into them with strided 2-D copies; no staging, no re-layout kernel, the rank's own
+    block is computed straight into its C_full.  RCCL cannot put two ranks on one device, so the end-of-step barrier
+    is the caller's (gloo) instead of the library's one-element all-reduce."""
+    import torch
+    import torch.distributed as dist
+
+    from hpc_amd import CSR, SpMMOpt, synth
+    from hpc_amd.dist import NativeColumnShardedSpMM, ShardLayout
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if kind == "powerlaw":
+            ptr, idx = synth.csr_powerlaw(M, 12.0, 3000, seed=21, force_max=True)
+        else:
+            ptr, idx = synth.csr_uniform(M, 0, 40, seed=5)
+        vals = synth.normal_f32(idx.size, 6)
+        blocks = [synth.normal_f32(M * n_loc, synth.SEED_B, stream=r).reshape(M, n_loc) for r in range(world)]
+        d_ptr, d_idx, d_val = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals))
+        B_loc = torch.from_numpy(blocks[rank]).to(dev)
+        C_full = torch.full((M, n_loc * world), float("nan"), device=dev)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
+        op.preprocess(B_loc, C_full)
+        sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=n_panels, exchange="peer2d")
+        sh.set_peers(C_full)
+        assert sh.get_option("has_peers") == 1 and sh.get_option("has_comm") == 0
+
+        def barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        for _ in range(3):
+            barrier()                     # nobody still reads the C_full we are about to write into
+            sh.run(B_loc, C_full)
+            barrier()                     # every rank's pushes have landed
+        B_all = torch.from_numpy(np.ascontiguousarray(np.concatenate(blocks, axis=1))).to(dev)
+        C_one = torch.empty(M, n_loc * world, device=dev)
+        one = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc * world)
+        one.set_option("long_row_threshold", op.get_option("long_row_threshold"))
+        one.preprocess(B_all, C_one)
+        one.run(B_all, C_one)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(C_full.view(torch.int32), C_one.view(torch.int32)))
+        q.put((rank, same, int(sh.get_option("staging_bytes")), int(torch.isnan(C_full).sum().item())))
+        barrier()                         # keep C_full mapped until every rank has compared
+        del sh
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,M,n_loc,n_panels,kind", [(2, 40000, 128, 8, "uniform"), (3, 30011, 64, 5, "powerlaw")])
+def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n_panels, kind):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, M, n_loc, n_panels, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=240) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, same, staging, nans in sorted(got):
+        assert staging == 0, "peer2d must not allocate staging"
+        assert nans == 0, f"rank {rank}: {nans} elements of C never written"
+        assert same, f"rank {rank}: C differs from the single-operator C"

@@ -52,6 +52,29 @@ def test_bitwise_over_tuning_knobs(device, oracle, block_threads, pol, N):
         assert np.array_equal(bits(C), bits(ref)), (rpb, xcd)
 
 
+@pytest.mark.parametrize("N", [64, 128, 256, 300, 1024])
+def test_bitwise_over_column_tile_widths(device, oracle, N):
+    """"tile_cols" (widest column tile of the rows / segment kernels; auto picks 64 for wide B with random columns and
+    whole-wave tiles for banded structure) is scheduling only: every width gives the oracle's bits -- short rows, medium
+    rows (one exact segment), split rows (documented piece order)."""
+    ptr, idx = synth.csr_powerlaw(3000, 30.0, 1200, K=20000, seed=77)
+    vals = synth.normal_f32(idx.size, 78)
+    B = synth.normal_f32(20000 * N, 79).reshape(20000, N)
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, 300, 64)
+    seen = set()
+    for tile in (0, 32, 64, 128, 256):
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"tile_cols": tile, "long_row_threshold": 300, "long_row_chunk": 64})
+        assert np.array_equal(bits(C), bits(exp)), tile
+        seen.add(op.get_option("lanes_per_row"))
+    assert len(seen) >= (2 if N == 64 else 3)
+    assert op.get_option("n_long_rows") > 0 and op.get_option("n_medium_rows") > 0
+    # the auto rule: random columns over K = 20000 are not "local"; a banded matrix is
+    assert 0 <= op.get_option("column_locality_pct") < 50
+    bp, bi = synth.csr_banded(30000, 4, 12, width=64, seed=5)
+    Cb, opb = run_spmm(device, bp, bi, synth.normal_f32(bi.size, 1), synth.normal_f32(30000 * 256, 2).reshape(30000, 256))
+    assert opb.get_option("column_locality_pct") > 90 and opb.get_option("lanes_per_row") == 64
+
+
 def test_edge_shapes(device, oracle):
     # M = 1; all rows empty; a single nonzero; K != M; nnz = 0
     for (M, K, N, lo, hi, seed) in [(1, 1, 4, 1, 1, 1), (5, 9, 8, 0, 0, 2), (1, 300, 128, 200, 200, 3), (300, 7, 16, 0, 7, 4), (64, 64, 128, 64, 64, 5)]:
@@ -576,6 +599,66 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d"])
+def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
+    """include/mi_spmm_dist.h on one GPU: a world of one with "rehearse" on runs the whole N > 1 machinery -- our own RCCL
+    communicator (ncclCommInitRank from a unique id), the panel pipeline over three streams, the in-place all-gather /
+    grouped send-recv into staging + the re-layout kernel, or the IPC / strided-copy path with its all-reduce
+    barriers -- and must give the plain operator's C; repeated steps reuse the staging buffers."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd.dist import NativeColumnShardedSpMM, ShardLayout
+
+    ptr, idx, vals, B, _ = _shared_list_case(70, 2500, 128, seed=99)      # block groups + ragged rows
+    g = np.random.Generator(np.random.Philox(key=[9, 9]))
+    extra = [np.sort(g.choice(2500, d, replace=False)).astype(np.int32) for d in (900, 120)]
+    idx = np.concatenate([idx] + extra)
+    ptr = np.concatenate([ptr, ptr[-1] + np.cumsum([e.size for e in extra])]).astype(np.int32)
+    vals = synth.normal_f32(idx.size, 3)
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), 128, num_cols=2500)
+    op.set_option("long_row_threshold", 256)
+    d_C = torch.full((M, 128), float("nan"), dtype=torch.float32, device=device)
+    op.preprocess(d_B, d_C)
+    sh = NativeColumnShardedSpMM(op, ShardLayout(M, 128, 1, 0), n_panels=3, exchange=exchange, rehearse=True)
+    sh.init_comm()
+    if exchange == "peer2d":
+        sh.set_peers(d_C)
+    assert sh.get_option("has_comm") == 1 and sh.get_option("n_panels") == 3
+    for _ in range(3):
+        sh.run(d_B, d_C)
+    torch.cuda.synchronize()
+    exp = oracle.spmm_chunked(ptr, idx, vals, B, 256, 256)
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    assert (sh.get_option("staging_bytes") > 0) == (exchange != "peer2d")
+    # the two legs on their own (bench.py's breakdown)
+    d_C.fill_(float("nan"))
+    sh.run_compute_only(d_B, d_C)
+    sh.run_exchange_only(d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    sh.set_option("n_panels", 1)
+    d_C.fill_(float("nan"))
+    sh.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+
+
+def test_native_dist_cpp_rehearsal(device):
+    """tests/native/dist_rehearsal.cpp: the C ABI driven from C++ (no Python, no torch) -- world of one over RCCL."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "dist_rehearsal")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "native")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for ex in ("allgather", "direct", "peer2d"):
+        assert f"exchange {ex}: bit-identical" in r.stdout, r.stdout
 
 
 def test_device_fill_matches_restatement(device, oracle):
