@@ -58,6 +58,31 @@ def set_threads(n):
     lib().oracle_set_threads(int(n))
 
 
+def try_native():
+    """bench.py's cpu_baseline leg: rebuild the restatement with -march=native ON THE BOX IT RUNS ON
+     and switch to it.  The shipped liboracle.so is built -march=x86-64-v3 in the CPU
+    container so that it also loads on the GPU box's host, which understates a Zen 5 host (no AVX-512).
+    Returns the compiler flags in force (the portable ones when gcc is missing or the build fails)."""
+    global _lib
+    portable = "gcc -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp"
+    out = os.path.join(_HERE, "_native", "liboracle_native.so")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", out,
+                               os.path.join(_HERE, "spmm_oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return portable
+    global LIB
+    keep_lib, keep_path = _lib, LIB
+    try:
+        _lib, LIB = None, out
+        lib()
+        return "gcc -O3 -march=native -ffp-contract=off -fopenmp (built on this host)"
+    except Exception:
+        _lib, LIB = keep_lib, keep_path
+        return portable
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -31,17 +31,22 @@ def test_single_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "rate_kind" in r and "split_mode" in r and r["tile_cols_in_force"] == 128
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0 and "march" in c["sample"]
+    assert d["ms_per_step_ref_protocol"] >= d["device_ms_per_step"] * 0.9      # util.h:141-151: 20 individually synchronised runs
     assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
     assert abs(d["value"] - 2.0 * d["config"]["nnz"] * d["config"]["N"] / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
 
 
-def test_multi_gpu_path_rehearsal():
-    d = _run("--rehearse-multi", "--no-cpu-baseline", "--check", "--panels", "3")
+@pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d"])
+def test_multi_gpu_path_rehearsal(exchange):
+    d = _run("--rehearse-multi", "--no-cpu-baseline", "--check", "--panels", "3", "--exchange", exchange)
     assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
     b = d["multi_gpu_breakdown"]
-    assert "error" not in b and b["compute_only_ms"] > 0 and b["allgather_plus_unpack_only_ms"] > 0
+    assert "error" not in b and b["compute_only_ms"] > 0 and b["exchange_only_ms"] > 0 and b["exchange"] == exchange
+    assert (b["staging_bytes"] > 0) == (exchange != "peer2d") and "strong_reference_ms" in d and d["strong_reference_ms"] > 0
     assert d["cpu_baseline"] is None
     r = d["roofline"]        # N>1: the same per-GPU kernel, timed on the compute-only leg
     assert r["bound"] == "hbm" and r["traffic"] is None and abs(r["kernel_ms"] - b["compute_only_ms"]) < 1e-3
@@ -61,5 +66,6 @@ def test_driver_launch_line_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["N"] == 256 and d["config"]["cols_per_gpu"] == 128
     assert "rehearsal" in d and d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
-    assert "error" not in d["multi_gpu_breakdown"]
+    assert "error" not in d["multi_gpu_breakdown"] and d["multi_gpu_breakdown"]["exchange"] == "peer2d"
+    assert d["strong_reference_ms"] > 0
     assert abs(d["value"] - 2.0 * d["config"]["nnz"] * 256 / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3

@@ -634,12 +634,14 @@ def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
     exp = oracle.spmm_chunked(ptr, idx, vals, B, 256, 256)
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
     assert (sh.get_option("staging_bytes") > 0) == (exchange != "peer2d")
-    # the two legs on their own (bench.py's breakdown)
+    # the two legs on their own (bench.py's breakdown: timing legs; with staging the panels share two buffers, so only
+    # the staging-free exchange leaves a complete C behind)
     d_C.fill_(float("nan"))
     sh.run_compute_only(d_B, d_C)
     sh.run_exchange_only(d_C)
     torch.cuda.synchronize()
-    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    if exchange == "peer2d":
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
     sh.set_option("n_panels", 1)
     d_C.fill_(float("nan"))
     sh.run(d_B, d_C)
