@@ -66,6 +66,7 @@ struct mi_spmm_handle {
     int64_t block_share;       // most pieces per item (1 = no sharing; default 2)
     int64_t block_max_pieces;  // most pieces a group's list is cut into = most passes (1 = never cut)
     int64_t block_run_min;     // shortest run worth a piece of its own
+    int64_t block_merge_unsafe; // A/B library only: all passes in ONE launch, dependencies ignored (timing experiment, wrong C)
     BlockItem *d_blk_items;
     int32_t n_blk_items, n_blk_pieces, n_blk_passes, n_blk_shared_items;
     // preprocess temporaries (grow-only, kept across preprocess calls, released by destroy)
@@ -157,15 +158,18 @@ static int build_block_items(mi_spmm_handle *h)
         keys.clear();
         for (int32_t gi = 0; gi < ng; ++gi) {
             const GroupPieces &g = gp[(size_t)gi];
-            if (g.n <= pass) continue;
-            Key k;
-            const int32_t c = g.c0[pass];
-            k.col = c >= 0 ? c : -1 - c;
-            k.len = g.len[pass];
-            k.gi = gi;
-            k.ord = pass;
-            k.shareable = c >= 0 && (g.len[pass] % kShareLenUnit) == 0 && share > 1;
-            keys.push_back(k);
+            for (int ord = 0; ord < g.n; ++ord) {
+                // (A/B library, "block_merge_unsafe": every ordinal lands in pass 0 -- one sweep, dependencies ignored)
+                if (h->block_merge_unsafe ? pass != 0 : ord != pass) continue;
+                Key k;
+                const int32_t c = g.c0[ord];
+                k.col = c >= 0 ? c : -1 - c;
+                k.len = g.len[ord];
+                k.gi = gi;
+                k.ord = ord;
+                k.shareable = c >= 0 && (g.len[ord] % kShareLenUnit) == 0 && share > 1;
+                keys.push_back(k);
+            }
         }
         if (keys.empty()) break;
         n_pass = pass + 1;
@@ -188,14 +192,15 @@ static int build_block_items(mi_spmm_handle *h)
             std::memset(&it, 0, sizeof(it));
             it.m = (int32_t)(j - i);
             const GroupPieces &g0 = gp[(size_t)keys[i].gi];
-            it.c0 = g0.c0[pass];
+            it.c0 = g0.c0[keys[i].ord];
             for (size_t q = i; q < j; ++q) {
                 const GroupPieces &g = gp[(size_t)keys[q].gi];
+                const int ord = keys[q].ord;
                 BlockPiece &p = it.p[q - i];
                 p.group = groups[(size_t)keys[q].gi];
-                p.k0 = g.k0[pass];
-                p.len = g.len[pass];
-                p.flags = (pass > 0 ? kPieceCarryIn : 0) | (pass + 1 < g.n ? kPieceCarryOut : 0);
+                p.k0 = g.k0[ord];
+                p.len = g.len[ord];
+                p.flags = (ord > 0 ? kPieceCarryIn : 0) | (ord + 1 < g.n ? kPieceCarryOut : 0);
                 p.p0 = ptr16[(size_t)keys[q].gi];
                 p.row_len = len16[(size_t)keys[q].gi];
                 ++n_pieces;
@@ -419,6 +424,9 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "block_share") { if (v < 1 || v > kMaxShare) return MI_SPMM_EINVAL; h->block_share = v; free_plan(h); }
     else if (k == "block_max_pieces") { if (v < 1 || v > kMaxPieces) return MI_SPMM_EINVAL; h->block_max_pieces = v; free_plan(h); }
     else if (k == "block_run_min") { if (v < 1) return MI_SPMM_EINVAL; h->block_run_min = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+#ifdef MI_SPMM_ABLATE
+    else if (k == "block_merge_unsafe") { h->block_merge_unsafe = v ? 1 : 0; free_plan(h); }
+#endif
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
 }
