@@ -125,9 +125,16 @@ const char *mi_spmm_strerror(int code);
  *   "nt_stream"           0/1: non-temporal loads of col_idx/vals
  *   "block_path"          0/1: 16-row groups sharing one column list go through the MFMA path
  *   "block_min_len"       shortest shared column list the block path takes
+ *   "block_max_pieces"    most runs of consecutive columns a group's list is cut into (1..4; 1 = never cut).  Run p of a
+ *                         group is processed in pass p, its fma chains continued through C: same bits, fewer B bytes
+ *   "block_run_min"       shortest run worth a piece (and a pass) of its own; a list with a shorter run stays whole
+ *   "block_share"         most pieces that share one fetch of their B rows (1 or 2)
  * set before preprocess; get any time.  Read-only keys after preprocess:
- *   "n_long_rows", "n_chunks", "workspace_bytes", "n_launches",
- *   "n_block_groups", "lanes_per_row", "preprocess_us" */
+ *   "n_long_rows", "n_chunks", "workspace_bytes", "n_launches", "lanes_per_row", "preprocess_us",
+ *   "n_block_groups", "n_block_pieces", "n_block_items", "n_block_shared_items", "n_block_passes",
+ *   "column_locality_pct" (share of sampled nonzeros near their row's own position; behind the "tile_cols" auto rule)
+ * Not in this library: "kernel" = 1 and "block_ablate" (first-generation / timing-only kernels) answer
+ * MI_SPMM_EUNSUPPORTED; they exist only in the A/B build (make -C hpc_amd/csrc ablate). */
 int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t value);
 int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value);
 
