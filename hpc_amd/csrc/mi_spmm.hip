@@ -151,7 +151,11 @@ static int build_block_items(mi_spmm_handle *h)
     }
     int32_t n_pass = 0, n_shared = 0;
     // shared items need the two-piece kernels, which exist for 256- and 128-column slabs (N % 128 == 0)
-    const int share = block_slab_width(h->feat) >= 128 ? (int)h->block_share : 1;
+    const int slab_w = block_slab_width(h->feat);
+    const int share = slab_w >= 128 ? (int)h->block_share : 1;
+    // the run kernels sweep whole trips (two k batches: 16 / 32 / 64 rows for 256- / 128- / narrower slabs) and fetch their A
+    // operands 16 bytes at a time; a run of any other length goes through the list kernel (general lengths, dword A loads)
+    const int run_unit = slab_w == 256 ? 16 : slab_w == 128 ? 32 : 64;
     std::vector<Key> keys;
     std::vector<BlockItem> lists, singles, shared;
     for (int pass = 0; pass < kMaxPieces; ++pass) {
@@ -162,7 +166,8 @@ static int build_block_items(mi_spmm_handle *h)
                 // (A/B library, "block_merge_unsafe": every ordinal lands in pass 0 -- one sweep, dependencies ignored)
                 if (h->block_merge_unsafe ? pass != 0 : ord != pass) continue;
                 Key k;
-                const int32_t c = g.c0[ord];
+                int32_t c = g.c0[ord];
+                if (c >= 0 && g.len[ord] % run_unit != 0) c = -1 - c;      // a run the run kernels cannot take: a list piece
                 k.col = c >= 0 ? c : -1 - c;
                 k.len = g.len[ord];
                 k.gi = gi;
@@ -193,6 +198,7 @@ static int build_block_items(mi_spmm_handle *h)
             it.m = (int32_t)(j - i);
             const GroupPieces &g0 = gp[(size_t)keys[i].gi];
             it.c0 = g0.c0[keys[i].ord];
+            if (it.c0 >= 0 && g0.len[keys[i].ord] % run_unit != 0) it.c0 = -1 - it.c0;
             for (size_t q = i; q < j; ++q) {
                 const GroupPieces &g = gp[(size_t)keys[q].gi];
                 const int ord = keys[q].ord;

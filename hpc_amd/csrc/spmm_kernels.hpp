@@ -704,11 +704,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
 
         // two register sets = two batches in flight.  Every float4 (float2) component is an MFMA B operand as it stands.
         BV R0[LOADS], R1[LOADS];
-        float a0[G][KS], a1[G][KS];
+        float a0[G][KS], a1[G][KS];                  // the A operands of the two sets (list items: loaded as such; run items: written by transpose_a)
         int cn0[KS], cn1[KS];                        // list items: this lane's columns of the batch a set will hold next
-        // one batch into one register set.  Lane (kq, i16) serves k-row kb + 4s + kq of step s.  Straight-line code and
-        // NOTHING touches a loaded value here: rows past the end of the longest piece are fetched from its last row and
-        // turned into zeros when the batch is computed (compute()), so the only wait for a set's loads is at its use,
+        constexpr int PAIR = 2 * KT;                 // k-rows per trip of the k loop (both sets)
+        constexpr int NA4 = PAIR / 16;               // run items: 16-byte A loads per piece and trip
+        float4v araw[G][NA4];                        // run items: the NEXT trip's A values as loaded (lane (kq, i16): A[i16][16g + 4kq .. +3])
+        // B operands of one batch into one register set.  Lane (kq, i16) serves k-row kb + 4s + kq of step s.  Straight-line code
+        // and NOTHING touches a loaded value here: rows past the end of the longest piece are fetched from its last row
+        // and (list items) turned into zeros when the batch is computed, so the only wait for a set's loads is at its use,
         // two batches later.  (A select right after the load -- or a conditional fetch -- made the compiler drain every
         // load at the bottom of the loop: no overlap at all.)
         auto fetch = [&](BV (&R)[LOADS], float (&af)[G][KS], int (&cn)[KS], int kb) {
@@ -726,12 +729,52 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
 #pragma unroll
                 for (int x = 0; x < XC; ++x) R[s * XC + x] = *reinterpret_cast<const BV *>(rowp + CW * x);
             }
+            if (!RUN) {
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const int k = kb + 4 * s + kq;
+                        af[j][s] = a.vals[rowstart[j] + ((j < np && k < slen[j]) ? k : 0)];
+                    }
+            }
+        };
+        // Run items (every piece a whole number of trips long -- the host sends other lengths to the list kernel): the A
+        // operands of a trip arrive as ONE 16-byte load per lane, piece and 16 k-rows -- lane (kq, i16) reads
+        // A[i16][kb + 16g + 4kq .. +3], 64 contiguous bytes per row -- instead of four dword loads that each touch 16 cache
+        // lines for 16 bytes apiece: the A side was half of the kernel's L2->L1 line traffic.  The MFMA wants lane kq to
+        // hold k = 4s + kq in step s: a 4 x 4 transpose across the four 16-lane rows, four v_permlane{32,16}_swap.
+        auto fetch_a = [&](int kb) {
 #pragma unroll
             for (int j = 0; j < G; ++j)
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int k = kb + 4 * s + kq;
-                    af[j][s] = a.vals[rowstart[j] + ((j < np && k < slen[j]) ? k : 0)];
+                for (int g = 0; g < NA4; ++g) {
+                    const int k = kb + 16 * g + 4 * kq;
+                    const int lj = (j < np) ? slen[j] : slen[0];
+                    const int rs = (j < np) ? rowstart[j] : rowstart[0];
+                    araw[j][g] = Vec<4>::load(a.vals + rs + (k + 4 <= lj ? k : lj - 4));     // past the end: re-read the last 16 bytes, never used
+                }
+        };
+        auto transpose_a = [&]() {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int g = 0; g < NA4; ++g) {
+                    const unsigned v0 = __float_as_uint(araw[j][g][0]), v1 = __float_as_uint(araw[j][g][1]);
+                    const unsigned v2 = __float_as_uint(araw[j][g][2]), v3 = __float_as_uint(araw[j][g][3]);
+                    // X[kq][c] = v_c in row kq.  permlane32_swap(a, b): rows 2,3 of a <-> rows 0,1 of b; permlane16_swap: odd rows of a <-> even rows of b.
+                    const auto r02 = __builtin_amdgcn_permlane32_swap(v0, v2, false, false);
+                    const auto r13 = __builtin_amdgcn_permlane32_swap(v1, v3, false, false);
+                    const auto s01 = __builtin_amdgcn_permlane16_swap(r02[0], r13[0], false, false);   // -> X[0][kq], X[1][kq]
+                    const auto s23 = __builtin_amdgcn_permlane16_swap(r02[1], r13[1], false, false);   // -> X[2][kq], X[3][kq]
+                    const float t[4] = {__uint_as_float(s01[0]), __uint_as_float(s01[1]), __uint_as_float(s23[0]), __uint_as_float(s23[1])};
+                    // step 4g + s of the trip: the first KS steps belong to set 0, the rest to set 1
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const int step = 4 * g + st;
+                        if (step < KS) a0[j][step] = t[st];
+                        else a1[j][step - KS] = t[st];
+                    }
                 }
         };
 #pragma unroll
@@ -740,13 +783,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
             cn0[s] = RUN ? 0 : a.col_idx[list0 + (k < L ? k : L - 1)];
             cn1[s] = RUN ? 0 : a.col_idx[list0 + (k + KT < L ? k + KT : L - 1)];
         }
+        if (RUN) fetch_a(0);
         fetch(R0, a0, cn0, 0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(R1, a1, cn1, KT);
         __builtin_amdgcn_sched_barrier(0);
 
-        // the MFMAs of one batch: every B operand feeds NA pieces.  Operands of k-rows past the end of a piece become
-        // zeros here (B: past the longest piece; A: past the piece's own end): 0 * 0 terms are exact no-ops.
+        // the MFMAs of one batch: every B operand feeds NA pieces.  List items: operands of k-rows past the end of the
+        // list become zeros here (0 * 0 terms are exact no-ops); run items never compute a batch past a piece's end.
         auto compute = [&](auto na_tag, const BV (&R)[LOADS], const float (&af)[G][KS], int kb) {
             constexpr int NA = decltype(na_tag)::value;
 #pragma unroll
@@ -754,45 +798,48 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
                 const int k = kb + 4 * s + kq;
                 float av[NA];
 #pragma unroll
-                for (int j = 0; j < NA; ++j) av[j] = (j < np && k < slen[j]) ? af[j][s] : 0.f;
+                for (int j = 0; j < NA; ++j) av[j] = (RUN || k < slen[j]) ? af[j][s] : 0.f;
 #pragma unroll
                 for (int x = 0; x < XC; ++x)
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
-                        const float bv = (k < L) ? R[s * XC + x][e] : 0.f;
+                        const float bv = (RUN || k < L) ? R[s * XC + x][e] : 0.f;
 #pragma unroll
                         for (int j = 0; j < NA; ++j) acc[j][V * x + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[j][V * x + e], 0, 0, 0);
                     }
             }
         };
-        // Two batches per trip: set 0, refill set 0 for the batch after next, set 1, refill set 1.  A refill past the end
-        // of the piece (at most two per item) re-reads the last row and is never used.
         // sched_barrier pins the ORDER compute(set 0) / refill set 0 / compute(set 1) / refill set 1: the machine scheduler
         // otherwise sinks both refills to the bottom of the loop with all A-operand loads last, and -- loads return in
         // order -- the wait for set 0's A operands at the top then waits for every B load: no overlap.
+        // Run items: a trip is a whole batch pair, so set 1's batch always exists; list items: it may be past the end (zeros).
         int kb = 0;
         if (G >= 2 && np >= 2) {
-            // both pieces run up to l1, a whole number of batch PAIRS (kShareLenUnit), l1 <= L
+            // both pieces run up to l1, a whole number of trips, l1 <= L
             const int l1 = slen[G >= 2 ? 1 : 0];
-            for (; kb < l1; kb += 2 * KT) {
+            for (; kb < l1; kb += PAIR) {
+                if (RUN) transpose_a();
                 compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R0, a0, kb);
                 __builtin_amdgcn_sched_barrier(0);
-                fetch(R0, a0, cn0, kb + 2 * KT);
+                fetch(R0, a0, cn0, kb + PAIR);
+                if (RUN) fetch_a(kb + PAIR);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(std::integral_constant<int, (G >= 2 ? 2 : 1)>{}, R1, a1, kb + KT);
                 __builtin_amdgcn_sched_barrier(0);
-                fetch(R1, a1, cn1, kb + 3 * KT);
+                fetch(R1, a1, cn1, kb + PAIR + KT);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        for (; kb < L; kb += 2 * KT) {
+        for (; kb < L; kb += PAIR) {
+            if (RUN) transpose_a();
             compute(std::integral_constant<int, 1>{}, R0, a0, kb);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(R0, a0, cn0, kb + 2 * KT);
+            fetch(R0, a0, cn0, kb + PAIR);
+            if (RUN) fetch_a(kb + PAIR);
             __builtin_amdgcn_sched_barrier(0);
-            compute(std::integral_constant<int, 1>{}, R1, a1, kb + KT);      // past the end: zero operands
+            compute(std::integral_constant<int, 1>{}, R1, a1, kb + KT);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(R1, a1, cn1, kb + 3 * KT);
+            fetch(R1, a1, cn1, kb + PAIR + KT);
             __builtin_amdgcn_sched_barrier(0);
         }
         // Epilogue: register q of the tiles (x, 0..V-1) leaves as V floats per lane, 16 lanes = one 64V-byte row segment,
