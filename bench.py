@@ -391,8 +391,8 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if not multi and os.path.exists(tp):
             try:
-                tj = json.load(open(tp))
-                if tj.get("config") == name:
+                tj = json.load(open(tp)).get(name)          # one entry per configuration (C1, C4, ...)
+                if tj and tj.get("N") == n_total:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = {"file": tj.get("source"), "commit": tj.get("commit"), "note": "measured by rocprofv3 --pmc passes of this "
                                       "command at that commit (scripts/prof.sh), not by this run; FETCH_SIZE x2 + WRITE_SIZE, L2 fabric side"}

@@ -960,4 +960,20 @@ def test_wide_addressing_variants(device, oracle):
         op.run_ld(d_B, ldb, d_C, N)
         torch.cuda.synchronize()
         assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)), rpb
+    del d_B, op
+    # the run kernels of the block path (shared items, passes) through the 64-bit-address variants as well
+    K2 = 210
+    ptr, idx, vals, Bs = _run_groups_case(60, K2, N, seed=909, lens=(32, 64), slots=3)
+    M = ptr.size - 1
+    d_ptr, d_idx, d_val = to_dev(device, ptr, idx, vals)
+    d_B = torch.zeros(K2 * ldb, device=device)                                         # 3.5 GB
+    d_B.view(K2, ldb)[:, :N] = torch.from_numpy(Bs).to(device)
+    d_C = torch.full((M, N), float("nan"), device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K2)
+    op.preprocess(d_B, d_C)
+    assert op.get_option("n_block_shared_items") > 0 and op.get_option("n_block_passes") >= 2
+    op.run_ld(d_B, ldb, d_C, N)
+    torch.cuda.synchronize()
+    assert op.get_option("wide_addressing") == 1
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(oracle.spmm_omp(ptr, idx, vals, Bs)))
     del d_B
