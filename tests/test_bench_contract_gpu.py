@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+def _run(*extra, **env_extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", **env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--M", "65536", "--steps", "3", "--warmup", "1", *extra],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -50,6 +50,15 @@ def test_multi_gpu_path_rehearsal(exchange):
     assert d["cpu_baseline"] is None
     r = d["roofline"]        # N>1: the same per-GPU kernel, timed on the compute-only leg
     assert r["bound"] == "hbm" and r["traffic"] is None and abs(r["kernel_ms"] - b["compute_only_ms"]) < 1e-3
+
+
+def test_multi_gpu_fallback_to_the_python_schedule():
+    """If the C-ABI step cannot be set up on some rank, every rank agrees to run the same schedule stated in Python over
+    torch.distributed (hpc_amd/dist.py ColumnShardedSpMM) and the line says so."""
+    d = _run("--rehearse-multi", "--no-cpu-baseline", "--check", "--panels", "3", MI_SPMM_FORCE_PY_DIST="1")
+    assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
+    b = d["multi_gpu_breakdown"]
+    assert "error" not in b and "fallback" in b["step_path"] and b["exchange"] == "allgather"
 
 
 def test_driver_launch_line_two_ranks_sharing_the_gpu():
