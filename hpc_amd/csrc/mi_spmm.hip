@@ -135,20 +135,6 @@ static int build_block_items(mi_spmm_handle *h)
     struct Key { int32_t col, len, gi, ord; bool shareable; };
     std::vector<BlockItem> items;
     int64_t n_pieces = 0;
-    std::vector<int32_t> ptr16((size_t)ng), len16((size_t)ng);   // row_ptr[16 g] and the common row length of every qualifying group
-    {
-        // two strided gathers from the device row_ptr: positions 16 g and 16 g + 1
-        std::vector<int32_t> pos((size_t)ng);
-        for (int32_t gi = 0; gi < ng; ++gi) pos[(size_t)gi] = groups[(size_t)gi] * 16;
-        // (one row_ptr copy is simpler than a gather kernel and is O(M) bytes once per preprocess)
-        std::vector<int32_t> ptr((size_t)h->num_v + 1);
-        e = hipMemcpy(ptr.data(), h->d_ptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return (int)e;
-        for (int32_t gi = 0; gi < ng; ++gi) {
-            ptr16[(size_t)gi] = ptr[(size_t)pos[(size_t)gi]];
-            len16[(size_t)gi] = ptr[(size_t)pos[(size_t)gi] + 1] - ptr[(size_t)pos[(size_t)gi]];
-        }
-    }
     int32_t n_pass = 0, n_shared = 0;
     // shared items need the two-piece kernels, which exist for 256- and 128-column slabs (N % 128 == 0)
     const int slab_w = block_slab_width(h->feat);
@@ -207,8 +193,8 @@ static int build_block_items(mi_spmm_handle *h)
                 p.k0 = g.k0[ord];
                 p.len = g.len[ord];
                 p.flags = (ord > 0 ? kPieceCarryIn : 0) | (ord + 1 < g.n ? kPieceCarryOut : 0);
-                p.p0 = ptr16[(size_t)keys[q].gi];
-                p.row_len = len16[(size_t)keys[q].gi];
+                p.p0 = g.p0;
+                p.row_len = g.row_len;
                 ++n_pieces;
             }
             // run items of one and of two pieces go through the same launch where the two-piece kernels exist: one long

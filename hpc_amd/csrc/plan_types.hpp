@@ -27,7 +27,9 @@ constexpr int kShareLenUnit = 32; // a run piece is shared only if its length is
 
 struct GroupPieces {              // analyze_group_runs output, one per qualifying group (64 bytes)
     int32_t n;                    // pieces: 1..kMaxPieces
-    int32_t pad[3];
+    int32_t p0;                   // row_ptr[16 g]
+    int32_t row_len;              // nonzeros per row of the group
+    int32_t pad;
     int32_t k0[kMaxPieces];       // position of the piece inside the group's column list
     int32_t c0[kMaxPieces];       // >= 0: first column of a run of consecutive columns; < 0: -1 - first column of a plain list piece
     int32_t len[kMaxPieces];

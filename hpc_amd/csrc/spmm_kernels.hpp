@@ -937,7 +937,9 @@ __global__ __launch_bounds__(kBlockThreads) void analyze_group_runs(const int32_
         o.len[0] = L;
         o.c0[0] = -1 - first_col;
     }
-    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    o.p0 = p0;
+    o.row_len = L;
+    o.pad = 0;
     out[gi] = o;
 }
 
