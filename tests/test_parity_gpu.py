@@ -843,6 +843,86 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
         assert np.isnan(got[:, N:]).all(), "wrote outside its N columns"
 
 
+def test_fuzz_block_items(device, oracle):
+    """Seeded random block structures through the item machinery: 1-4 runs per group of arbitrary start / length (aligned or
+    not to the k batches), plain lists, groups that miss qualifying by one column, every slab width, row pitches, random
+    option combinations, ragged row-range calls -- always the oracle's bits."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    n_cases = int(os.environ.get("MI_SPMM_BLOCK_FUZZ_CASES", "40"))       # soak: MI_SPMM_BLOCK_FUZZ_CASES=400
+    seen = {"groups": 0, "shared": 0, "multi_pass": 0, "panels": 0}
+    g = np.random.Generator(np.random.Philox(key=[4040, int(os.environ.get("MI_SPMM_FUZZ_SEED", "1"))]))
+    for case in range(n_cases):
+        K = int(g.integers(1200, 2600))
+        N = int(g.choice([32, 64, 96, 128, 160, 256, 288, 384, 512]))
+        n_groups = int(g.integers(3, 40))
+        starts_pool = np.sort(g.choice((K - 140) // 160, size=int(g.integers(2, 6)), replace=False)) * 160   # far enough apart never to collide
+        ptr, idx = [0], []
+        for b in range(n_groups):
+            kind = int(g.integers(0, 5))
+            if kind <= 2:                                     # runs from a small pool of starts (sharing), lengths of every residue
+                nr = int(g.integers(1, 5))
+                st = np.sort(g.choice(starts_pool, size=min(nr, starts_pool.size), replace=False))
+                cols, last = [], -1
+                for q in st:
+                    L = int(g.choice([32, 64, 96, 128, 32, 64, 16, 33, 40, 48, 7, 100]))
+                    q = max(int(q), last + 2)                 # keep the runs apart (a gap of at least one column)
+                    if q + L > K:
+                        continue
+                    cols.append(np.arange(q, q + L))
+                    last = q + L
+                cols = np.concatenate(cols).astype(np.int32) if cols else g.integers(0, K, size=9).astype(np.int32)
+            elif kind == 3:
+                cols = g.integers(0, K, size=int(g.integers(8, 120))).astype(np.int32)
+            else:
+                cols = None
+            for r in range(16):
+                if cols is None:
+                    c = np.sort(g.choice(K, int(g.integers(0, 30)), replace=False)).astype(np.int32)
+                else:
+                    c = cols.copy()
+                    if kind == 2 and b % 5 == 0 and r == 9:
+                        c[c.size // 2] = (c[c.size // 2] + 1) % K      # one row differs: the group must NOT qualify
+                idx.append(c)
+                ptr.append(ptr[-1] + c.size)
+        for _ in range(int(g.integers(0, 9))):                # M not a multiple of 16
+            c = np.sort(g.choice(K, int(g.integers(1, 20)), replace=False)).astype(np.int32)
+            idx.append(c)
+            ptr.append(ptr[-1] + c.size)
+        ptr = np.asarray(ptr, np.int32)
+        idx = np.concatenate(idx).astype(np.int32)
+        vals = synth.normal_f32(idx.size, 7000 + case)
+        M = ptr.size - 1
+        ldb = N + int(g.choice([0, 0, 4, 64]))
+        ldc = N + int(g.choice([0, 0, 4, 128]))
+        Bp = synth.normal_f32(K * ldb, 8000 + case).reshape(K, ldb)
+        opts = {"long_row_threshold": int(g.choice([256, 2048])), "block_share": int(g.choice([1, 2])), "block_max_pieces": int(g.choice([1, 2, 4])),
+                "block_run_min": int(g.choice([8, 32, 64])), "block_min_len": int(g.choice([8, 30]))}
+        d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
+        d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+        for k, v in opts.items():
+            op.set_option(k, v)
+        op.preprocess(d_B, d_C)
+        if g.random() < 0.4 and M > 2:
+            cuts = sorted(set([0, M] + [int(x) for x in g.integers(0, M, 3)]))
+            for r0, r1 in zip(cuts, cuts[1:]):
+                op.run_rows(d_B, ldb, d_C, ldc, r0, r1)
+        else:
+            op.run_ld(d_B, ldb, d_C, ldc)
+            op.run_ld(d_B, ldb, d_C, ldc)              # a second step over the carried tiles of the first
+        torch.cuda.synchronize()
+        got = d_C.cpu().numpy()
+        exp = oracle.spmm_chunked(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["long_row_threshold"], 256)
+        assert np.array_equal(bits(got[:, :N]), bits(exp)), (case, M, K, N, ldb, ldc, opts, op.get_option("n_block_groups"), op.get_option("n_block_passes"))
+        assert np.isnan(got[:, N:]).all(), "wrote outside its N columns"
+        seen["groups"] += op.get_option("n_block_groups")
+        seen["shared"] += op.get_option("n_block_shared_items")
+        seen["multi_pass"] += 1 if op.get_option("n_block_passes") > 1 else 0
+    assert seen["groups"] > 5 * n_cases and seen["shared"] > n_cases // 8 and seen["multi_pass"] > n_cases // 4, seen
+
+
 def test_special_values_all_paths(device, oracle):
     """inf, NaN, -0.0 and subnormals in A and B through the rows, segment (medium + split) and MFMA block
     paths: same bits as the oracle (NaNs compared as NaN: payloads are not part of the contract).
