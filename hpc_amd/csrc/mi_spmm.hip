@@ -73,6 +73,19 @@ struct mi_spmm_handle {
     Scratch scratch_a, scratch_b;
     unsigned int *d_col_bad;   // 256 bytes: the column-range flag
     struct { int32_t off, n; } blk_launch[kMaxPieces][3];   // [pass][0: list items, 1: run items of one piece, 2: shared run items]
+#ifdef MI_SPMM_ABLATE
+    // EXPERIMENT (A/B library): B-stationary sweeps (spmm_block_sweep) -- the run pieces laid on tracks, and the items of what is left over
+    int64_t block_sweep;            // 1: full-row-range steps on 256-column slabs sweep; 0: items only
+    int64_t block_sweep_cols;       // segment length in columns (pieces STARTING in a segment share its workgroups)
+    int64_t block_sweep_min_tracks; // a workgroup with fewer tracks is not worth its B loads: those pieces stay items
+    SweepWG *d_sweep_wgs;
+    int32_t *d_sweep_cols;
+    SweepEnt *d_sweep_ents;
+    BlockItem *d_blk_res_items;
+    int32_t n_sweep_wgs, n_sweep_pieces, n_sweep_trips, n_blk_res_items;
+    struct { int32_t off, n; } sweep_launch[kMaxPieces];
+    struct { int32_t off, n; } blk_res_launch[kMaxPieces][3];
+#endif
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
@@ -93,6 +106,19 @@ static void free_plan(mi_spmm_handle *h)
     h->d_blk_items = nullptr;
     h->n_blk_items = h->n_blk_pieces = h->n_blk_passes = h->n_blk_shared_items = 0;
     std::memset(h->blk_launch, 0, sizeof(h->blk_launch));
+#ifdef MI_SPMM_ABLATE
+    if (h->d_sweep_wgs) (void)hipFree(h->d_sweep_wgs);
+    if (h->d_sweep_cols) (void)hipFree(h->d_sweep_cols);
+    if (h->d_sweep_ents) (void)hipFree(h->d_sweep_ents);
+    if (h->d_blk_res_items) (void)hipFree(h->d_blk_res_items);
+    h->d_sweep_wgs = nullptr;
+    h->d_sweep_cols = nullptr;
+    h->d_sweep_ents = nullptr;
+    h->d_blk_res_items = nullptr;
+    h->n_sweep_wgs = h->n_sweep_pieces = h->n_sweep_trips = h->n_blk_res_items = 0;
+    std::memset(h->sweep_launch, 0, sizeof(h->sweep_launch));
+    std::memset(h->blk_res_launch, 0, sizeof(h->blk_res_launch));
+#endif
     h->d_blk_flag = nullptr;
     h->d_blk_groups = nullptr;
     h->n_blk_groups = 0;
@@ -132,18 +158,127 @@ static int build_block_items(mi_spmm_handle *h)
     (void)hipFree(d_gp);
     if (e != hipSuccess) return (int)e;
 
-    struct Key { int32_t col, len, gi, ord; bool shareable; };
-    std::vector<BlockItem> items;
-    int64_t n_pieces = 0;
-    int32_t n_pass = 0, n_shared = 0;
     // shared items need the two-piece kernels, which exist for 256- and 128-column slabs (N % 128 == 0)
     const int slab_w = block_slab_width(h->feat);
     const int share = slab_w >= 128 ? (int)h->block_share : 1;
     // the run kernels sweep whole trips (two k batches: 16 / 32 / 64 rows for 256- / 128- / narrower slabs) and fetch their A
     // operands 16 bytes at a time; a run of any other length goes through the list kernel (general lengths, dword A loads)
     const int run_unit = slab_w == 256 ? 16 : slab_w == 128 ? 32 : 64;
-    std::vector<Key> keys;
+#ifdef MI_SPMM_ABLATE
+    const bool sweeping = h->block_sweep != 0 && slab_w == 256 && !h->block_merge_unsafe;   // experiment: spmm_block_sweep
+    const int32_t seg_cols = (int32_t)h->block_sweep_cols;
+#endif
+
+    struct Key { int32_t col, len, gi, ord; bool shareable, run; };
+    struct Launch { int32_t off, n; };
+    std::vector<BlockItem> items;
+    int64_t n_pieces = 0;
+    int32_t n_pass = 0, n_shared = 0;
+    std::vector<Key> keys, rest;
     std::vector<BlockItem> lists, singles, shared;
+
+    auto piece_of = [&](const Key &k) {
+        const GroupPieces &g = gp[(size_t)k.gi];
+        BlockPiece p;
+        p.group = groups[(size_t)k.gi];
+        p.k0 = g.k0[k.ord];
+        p.len = g.len[k.ord];
+        p.flags = (k.ord > 0 ? kPieceCarryIn : 0) | (k.ord + 1 < g.n ? kPieceCarryOut : 0);
+        p.p0 = g.p0;
+        p.row_len = g.row_len;
+        return p;
+    };
+    // one pass's keys -> its items, appended to `out` class by class (lists, singles, shared)
+    auto form_items = [&](std::vector<Key> &ks, std::vector<BlockItem> &out, Launch (&launch)[3], bool count) {
+        // by first column; among equals the shareable ones together, longest first; ties in group order (deterministic)
+        std::sort(ks.begin(), ks.end(), [](const Key &x, const Key &y) {
+            if (x.col != y.col) return x.col < y.col;
+            if (x.shareable != y.shareable) return x.shareable > y.shareable;
+            if (x.len != y.len) return x.len > y.len;
+            return x.gi < y.gi;
+        });
+        lists.clear();
+        singles.clear();
+        shared.clear();
+        size_t i = 0;
+        while (i < ks.size()) {
+            size_t j = i + 1;
+            if (ks[i].shareable)
+                while (j < ks.size() && j - i < (size_t)share && ks[j].shareable && ks[j].col == ks[i].col) ++j;
+            BlockItem it;
+            std::memset(&it, 0, sizeof(it));
+            it.m = (int32_t)(j - i);
+            it.c0 = ks[i].run ? ks[i].col : -1 - ks[i].col;
+            for (size_t q = i; q < j; ++q) it.p[q - i] = piece_of(ks[q]);
+            // run items of one and of two pieces go through the same launch where the two-piece kernels exist: one long
+            // list in column order instead of two short ones (a short launch pays its tail on 256 CUs)
+            (it.c0 < 0 ? lists : (it.m > 1 || share > 1) ? shared : singles).push_back(it);
+            if (count) {
+                n_pieces += it.m;
+                if (it.m > 1) ++n_shared;
+            }
+            i = j;
+        }
+        std::vector<BlockItem> *cls[3] = {&lists, &singles, &shared};
+        for (int c = 0; c < 3; ++c) {
+            launch[c].off = (int32_t)out.size();
+            launch[c].n = (int32_t)cls[c]->size();
+            out.insert(out.end(), cls[c]->begin(), cls[c]->end());
+        }
+    };
+#ifdef MI_SPMM_ABLATE
+    // The sweepable keys of one pass -> tracks -> workgroups.  Pieces are taken in (first column, longest first) order; the
+    // ones starting in the same segment of seg_cols columns are interval-partitioned: a piece goes on the track that ended
+    // last at or before its first column (best fit), or opens a new one.  kSweepTracks tracks make a workgroup; a
+    // segment's last few tracks, too few to pay for a workgroup's B loads, hand their pieces back (-> items).
+    struct Track { int32_t end; int64_t cols; std::vector<Key> ks; };
+    struct WGPlan { std::vector<Key> tr[kSweepTracks]; };
+    std::vector<Track> tracks;
+    auto form_sweeps = [&](std::vector<Key> &ks, std::vector<Key> &back, std::vector<WGPlan> &out) {
+        std::sort(ks.begin(), ks.end(), [](const Key &x, const Key &y) {
+            if (x.col != y.col) return x.col < y.col;
+            if (x.len != y.len) return x.len > y.len;
+            return x.gi < y.gi;
+        });
+        size_t i = 0;
+        while (i < ks.size()) {
+            const int32_t seg = ks[i].col / seg_cols;
+            size_t j = i;
+            tracks.clear();
+            for (; j < ks.size() && ks[j].col / seg_cols == seg; ++j) {
+                int best = -1;
+                for (size_t t = 0; t < tracks.size(); ++t)
+                    if (tracks[t].end <= ks[j].col && (best < 0 || tracks[t].end > tracks[(size_t)best].end)) best = (int)t;
+                if (best < 0) {
+                    tracks.emplace_back();
+                    best = (int)tracks.size() - 1;
+                    tracks[(size_t)best].cols = 0;
+                }
+                tracks[(size_t)best].end = ks[j].col + ks[j].len;
+                tracks[(size_t)best].cols += ks[j].len;
+                tracks[(size_t)best].ks.push_back(ks[j]);
+            }
+            // fullest tracks first, so that the workgroup that may be dropped holds the least
+            std::stable_sort(tracks.begin(), tracks.end(), [](const Track &x, const Track &y) { return x.cols > y.cols; });
+            for (size_t t0 = 0; t0 < tracks.size(); t0 += kSweepTracks) {
+                const size_t t1 = std::min(tracks.size(), t0 + (size_t)kSweepTracks);
+                if ((int64_t)(t1 - t0) < h->block_sweep_min_tracks) {
+                    for (size_t t = t0; t < t1; ++t) back.insert(back.end(), tracks[t].ks.begin(), tracks[t].ks.end());
+                    continue;
+                }
+                out.emplace_back();
+                // waves hold tracks (2w, 2w+1): deal the tracks out so that every wave gets a full one before any gets two
+                for (size_t t = t0; t < t1; ++t) out.back().tr[((t - t0) % 4) * 2 + (t - t0) / 4] = std::move(tracks[t].ks);
+            }
+            i = j;
+        }
+    };
+
+#endif
+#ifdef MI_SPMM_ABLATE
+    std::vector<BlockItem> res_items;
+    std::vector<std::vector<Key>> pass_keys;
+#endif
     for (int pass = 0; pass < kMaxPieces; ++pass) {
         keys.clear();
         for (int32_t gi = 0; gi < ng; ++gi) {
@@ -152,73 +287,141 @@ static int build_block_items(mi_spmm_handle *h)
                 // (A/B library, "block_merge_unsafe": every ordinal lands in pass 0 -- one sweep, dependencies ignored)
                 if (h->block_merge_unsafe ? pass != 0 : ord != pass) continue;
                 Key k;
-                int32_t c = g.c0[ord];
-                if (c >= 0 && g.len[ord] % run_unit != 0) c = -1 - c;      // a run the run kernels cannot take: a list piece
+                const int32_t c = g.c0[ord];
+                k.run = c >= 0 && g.len[ord] % run_unit == 0;      // any other run the run kernels cannot take: a list piece
                 k.col = c >= 0 ? c : -1 - c;
                 k.len = g.len[ord];
                 k.gi = gi;
                 k.ord = ord;
-                k.shareable = c >= 0 && (g.len[ord] % kShareLenUnit) == 0 && share > 1;
+                k.shareable = k.run && (g.len[ord] % kShareLenUnit) == 0 && share > 1;
                 keys.push_back(k);
             }
         }
         if (keys.empty()) break;
         n_pass = pass + 1;
-        // by first column; among equals the shareable ones together, longest first; ties in group order (deterministic)
-        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-            if (a.col != b.col) return a.col < b.col;
-            if (a.shareable != b.shareable) return a.shareable > b.shareable;
-            if (a.len != b.len) return a.len > b.len;
-            return a.gi < b.gi;
-        });
-        lists.clear();
-        singles.clear();
-        shared.clear();
-        size_t i = 0;
-        while (i < keys.size()) {
-            size_t j = i + 1;
-            if (keys[i].shareable)
-                while (j < keys.size() && j - i < (size_t)share && keys[j].shareable && keys[j].col == keys[i].col) ++j;
-            BlockItem it;
-            std::memset(&it, 0, sizeof(it));
-            it.m = (int32_t)(j - i);
-            const GroupPieces &g0 = gp[(size_t)keys[i].gi];
-            it.c0 = g0.c0[keys[i].ord];
-            if (it.c0 >= 0 && g0.len[keys[i].ord] % run_unit != 0) it.c0 = -1 - it.c0;
-            for (size_t q = i; q < j; ++q) {
-                const GroupPieces &g = gp[(size_t)keys[q].gi];
-                const int ord = keys[q].ord;
-                BlockPiece &p = it.p[q - i];
-                p.group = groups[(size_t)keys[q].gi];
-                p.k0 = g.k0[ord];
-                p.len = g.len[ord];
-                p.flags = (ord > 0 ? kPieceCarryIn : 0) | (ord + 1 < g.n ? kPieceCarryOut : 0);
-                p.p0 = g.p0;
-                p.row_len = g.row_len;
-                ++n_pieces;
-            }
-            // run items of one and of two pieces go through the same launch where the two-piece kernels exist: one long
-            // list in column order instead of two short ones (a short launch pays its tail on 256 CUs)
-            (it.c0 < 0 ? lists : (it.m > 1 || share > 1) ? shared : singles).push_back(it);
-            if (it.m > 1) ++n_shared;
-            i = j;
-        }
-        std::vector<BlockItem> *cls[3] = {&lists, &singles, &shared};
-        for (int c = 0; c < 3; ++c) {
-            h->blk_launch[pass][c].off = (int32_t)items.size();
-            h->blk_launch[pass][c].n = (int32_t)cls[c]->size();
-            items.insert(items.end(), cls[c]->begin(), cls[c]->end());
-        }
+#ifdef MI_SPMM_ABLATE
+        if (sweeping) pass_keys.push_back(keys);
+#endif
+        Launch al[3];
+        form_items(keys, items, al, true);
+        for (int c = 0; c < 3; ++c) { h->blk_launch[pass][c].off = al[c].off; h->blk_launch[pass][c].n = al[c].n; }
     }
     if (items.empty()) return MI_SPMM_OK;
-    if (hipMalloc((void **)&h->d_blk_items, items.size() * sizeof(BlockItem)) != hipSuccess) return MI_SPMM_ENOMEM;
-    e = hipMemcpy(h->d_blk_items, items.data(), items.size() * sizeof(BlockItem), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return (int)e;
+
+#ifdef MI_SPMM_ABLATE
+    // The second plan, used by full-row-range steps: sweeps + the items of everything the sweeps do not take.  A group
+    // rides the sweeps with ALL of its pieces or with none (carried tiles between sweep passes are register images).
+    std::vector<SweepWG> wgs;
+    std::vector<int32_t> trip_cols;
+    std::vector<SweepEnt> ents;
+    int32_t n_sweep_pieces = 0;
+    if (sweeping) {
+        std::vector<std::vector<WGPlan>> plans((size_t)n_pass);
+        std::vector<std::vector<Key>> rests((size_t)n_pass);
+        std::vector<uint8_t> riding((size_t)ng, 0);
+        for (int pass = 0; pass < n_pass; ++pass) {
+            std::vector<Key> sw;
+            for (const Key &k : pass_keys[(size_t)pass]) {
+                const bool ok = k.run && k.col % kSweepTrip == 0 && k.len % kSweepTrip == 0 && gp[(size_t)k.gi].row_len < (1 << 24);
+                (ok ? sw : rests[(size_t)pass]).push_back(k);
+            }
+            form_sweeps(sw, rests[(size_t)pass], plans[(size_t)pass]);
+            for (const WGPlan &w : plans[(size_t)pass])
+                for (const auto &tr : w.tr)
+                    for (const Key &k : tr) riding[(size_t)k.gi] |= (uint8_t)(1u << k.ord);
+        }
+        for (int32_t gi = 0; gi < ng; ++gi)         // all or nothing
+            if (riding[(size_t)gi] != (uint8_t)((1u << gp[(size_t)gi].n) - 1u)) riding[(size_t)gi] = 0;
+        std::vector<std::pair<int32_t, int32_t>> iv;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            h->sweep_launch[pass].off = (int32_t)wgs.size();
+            for (WGPlan &w : plans[(size_t)pass]) {
+                iv.clear();
+                for (auto &tr : w.tr) {
+                    size_t keep = 0;
+                    for (const Key &k : tr) {
+                        if (riding[(size_t)k.gi]) tr[keep++] = k;
+                        else rests[(size_t)pass].push_back(k);
+                    }
+                    tr.resize(keep);
+                    for (const Key &k : tr) iv.emplace_back(k.col, k.col + k.len);
+                }
+                if (iv.empty()) continue;
+                std::sort(iv.begin(), iv.end());
+                SweepWG rec;
+                rec.trip_begin = (int32_t)trip_cols.size();
+                // the trips: every 16 columns of the union of the tracks' pieces; per trip and track, what the track does
+                size_t cur[kSweepTracks] = {0};
+                int32_t sb = iv[0].first, se = iv[0].second;
+                auto emit_span = [&](int32_t b0, int32_t e0) {
+                    for (int32_t col = b0; col < e0; col += kSweepTrip) {
+                        trip_cols.push_back(col);
+                        for (int t = 0; t < kSweepTracks; ++t) {
+                            SweepEnt en = {-1, 0, 0, 0};
+                            const std::vector<Key> &tr = w.tr[t];
+                            while (cur[t] < tr.size() && tr[cur[t]].col + tr[cur[t]].len <= col) ++cur[t];
+                            if (cur[t] < tr.size() && tr[cur[t]].col <= col) {
+                                const Key &k = tr[cur[t]];
+                                const BlockPiece bp = piece_of(k);
+                                en.group = bp.group;
+                                en.flags = (col == k.col ? kSweepFirst : 0) | (col + kSweepTrip == k.col + k.len ? kSweepLast : 0) |
+                                           ((bp.flags & kPieceCarryIn) ? kSweepCarryIn : 0) | ((bp.flags & kPieceCarryOut) ? kSweepCarryOut : 0);
+                                en.a_off = bp.p0 + bp.k0 + (col - k.col);
+                                en.row_len = bp.row_len;
+                            }
+                            ents.push_back(en);
+                        }
+                    }
+                };
+                for (size_t q = 1; q < iv.size(); ++q) {
+                    if (iv[q].first <= se) se = std::max(se, iv[q].second);
+                    else {
+                        emit_span(sb, se);
+                        sb = iv[q].first;
+                        se = iv[q].second;
+                    }
+                }
+                emit_span(sb, se);
+                rec.n_trips = (int32_t)trip_cols.size() - rec.trip_begin;
+                wgs.push_back(rec);
+                n_sweep_pieces += (int32_t)iv.size();
+            }
+            h->sweep_launch[pass].n = (int32_t)wgs.size() - h->sweep_launch[pass].off;
+            Launch rl[3];
+            form_items(rests[(size_t)pass], res_items, rl, false);
+            for (int c = 0; c < 3; ++c) { h->blk_res_launch[pass][c].off = rl[c].off; h->blk_res_launch[pass][c].n = rl[c].n; }
+        }
+    }
+
+#endif
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
+        if (bytes == 0) return MI_SPMM_OK;
+        if (hipMalloc(dst, bytes) != hipSuccess) return MI_SPMM_ENOMEM;
+        const hipError_t ue = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        if (ue != hipSuccess) return (int)ue;
+        h->ws_bytes += bytes;
+        return MI_SPMM_OK;
+    };
+    int rc = upload((void **)&h->d_blk_items, items.data(), items.size() * sizeof(BlockItem));
+#ifdef MI_SPMM_ABLATE
+    if (rc == MI_SPMM_OK && !wgs.empty()) {
+        rc = upload((void **)&h->d_sweep_wgs, wgs.data(), wgs.size() * sizeof(SweepWG));
+        if (rc == MI_SPMM_OK) rc = upload((void **)&h->d_sweep_cols, trip_cols.data(), trip_cols.size() * sizeof(int32_t));
+        if (rc == MI_SPMM_OK) rc = upload((void **)&h->d_sweep_ents, ents.data(), ents.size() * sizeof(SweepEnt));
+        if (rc == MI_SPMM_OK) rc = upload((void **)&h->d_blk_res_items, res_items.data(), res_items.size() * sizeof(BlockItem));
+    }
+#endif
+    if (rc != MI_SPMM_OK) return rc;
+#ifdef MI_SPMM_ABLATE
+    h->n_sweep_pieces = n_sweep_pieces;
+    h->n_sweep_wgs = (int32_t)wgs.size();
+    h->n_sweep_trips = (int32_t)std::min<size_t>(trip_cols.size(), (size_t)INT32_MAX);
+    h->n_blk_res_items = (int32_t)res_items.size();
+#endif
     h->n_blk_items = (int32_t)items.size();
     h->n_blk_pieces = (int32_t)n_pieces;
     h->n_blk_passes = n_pass;
     h->n_blk_shared_items = n_shared;
-    h->ws_bytes += items.size() * sizeof(BlockItem);
     return MI_SPMM_OK;
 }
 
@@ -354,6 +557,11 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->block_share = 2;
     h->block_max_pieces = kMaxPieces;
     h->block_run_min = 32;
+#ifdef MI_SPMM_ABLATE
+    h->block_sweep = 0;
+    h->block_sweep_cols = 2048;
+    h->block_sweep_min_tracks = 5;
+#endif
     h->kernel = 2;
     h->gpu_preprocess = 1;
     h->block_threads = 256;
@@ -418,6 +626,9 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "block_run_min") { if (v < 1) return MI_SPMM_EINVAL; h->block_run_min = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
 #ifdef MI_SPMM_ABLATE
     else if (k == "block_merge_unsafe") { h->block_merge_unsafe = v ? 1 : 0; free_plan(h); }
+    else if (k == "block_sweep") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->block_sweep = v; free_plan(h); }
+    else if (k == "block_sweep_cols") { if (v < kSweepTrip || v > (1 << 24) || v % kSweepTrip != 0) return MI_SPMM_EINVAL; h->block_sweep_cols = v; free_plan(h); }
+    else if (k == "block_sweep_min_tracks") { if (v < 1 || v > kSweepTracks) return MI_SPMM_EINVAL; h->block_sweep_min_tracks = v; free_plan(h); }
 #endif
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
@@ -461,6 +672,15 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_block_pieces") *value = h->n_blk_pieces;
     else if (k == "n_block_passes") *value = h->n_blk_passes;
     else if (k == "n_block_shared_items") *value = h->n_blk_shared_items;
+#ifdef MI_SPMM_ABLATE
+    else if (k == "block_sweep") *value = h->block_sweep;
+    else if (k == "block_sweep_cols") *value = h->block_sweep_cols;
+    else if (k == "block_sweep_min_tracks") *value = h->block_sweep_min_tracks;
+    else if (k == "n_sweep_workgroups") *value = h->n_sweep_wgs;
+    else if (k == "n_sweep_pieces") *value = h->n_sweep_pieces;
+    else if (k == "n_sweep_trips") *value = h->n_sweep_trips;
+    else if (k == "n_block_residual_items") *value = h->n_blk_res_items;
+#endif
     else if (k == "preprocess_us") *value = (int64_t)h->preprocess_us;
     else if (k == "pre_d2h_us") *value = (int64_t)h->phase_us[0];
     else if (k == "pre_colcheck_us") *value = (int64_t)h->phase_us[1];
@@ -891,12 +1111,42 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ba.row_lo = row_begin;
         ba.row_hi = row_end;
         const int slab = block_slab_width(full.N), slabs = full.N / slab;
+#ifdef MI_SPMM_ABLATE
+        // full-row-range steps on 256-column slabs: the run pieces are swept on tracks, the items are what is left over
+        const bool sweep = h->n_sweep_wgs > 0 && slab == 256 && row_begin <= 0 && row_end >= h->num_v;
+        SweepArgs sa;
+        sa.wgs = nullptr;
+        sa.cols = h->d_sweep_cols;
+        sa.ents = h->d_sweep_ents;
+        sa.vals = h->d_val;
+        sa.B = full.B;
+        sa.C = full.C;
+        sa.ldb = ldb;
+        sa.ldc = ldc;
+        sa.n_wgs = 0;
+        sa.remap = remap_blocks ? 1 : 0;
+#endif
         // pass p continues the fma chains pass p-1 left in C: stream order is the dependency
         for (int pass = 0; pass < h->n_blk_passes; ++pass) {
+#ifdef MI_SPMM_ABLATE
+            if (sweep && h->sweep_launch[pass].n > 0) {
+                sa.wgs = h->d_sweep_wgs + h->sweep_launch[pass].off;
+                sa.n_wgs = h->sweep_launch[pass].n;
+                dim3 sgrid((unsigned)sa.n_wgs, slabs);
+                hipLaunchKernelGGL(spmm_block_sweep, sgrid, dim3(kBlockThreads), 0, s, sa);
+                ++launches;
+            }
+#endif
             for (int cls = 2; cls >= 0; --cls) {
-                const int32_t n = h->blk_launch[pass][cls].n;
-                if (n == 0) continue;
+                int32_t n = h->blk_launch[pass][cls].n;
                 ba.items = h->d_blk_items + h->blk_launch[pass][cls].off;
+#ifdef MI_SPMM_ABLATE
+                if (sweep) {
+                    n = h->blk_res_launch[pass][cls].n;
+                    ba.items = h->d_blk_res_items + h->blk_res_launch[pass][cls].off;
+                }
+#endif
+                if (n == 0) continue;
                 ba.n_items = n;
                 dim3 bgrid((unsigned)((n + 3) / 4), slabs);
                 launch_block_items(slab, cls, wide_full, ba, bgrid, s);

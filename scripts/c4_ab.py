@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--one", type=int, nargs=2, default=None)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--sweep", action="store_true", help="items vs B-stationary sweeps (block_sweep; A/B library: MI_SPMM_LIB=hpc_amd/libmi_spmm_ablate.so) at several segment lengths / track floors")
     args = ap.parse_args()
     import torch
     from hpc_amd import CSR, SpMMOpt, synth
@@ -42,11 +43,13 @@ def main():
     d_B = torch.empty(M * N, dtype=torch.float32, device=dev)
     fill_normal(d_B, seed=125)
 
-    def make(share, pieces):
+    def make(share, pieces, extra=()):
         d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
         op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), N)
         op.set_option("block_share", share)
         op.set_option("block_max_pieces", pieces)
+        for k, v in extra:
+            op.set_option(k, v)
         for kv in args.opt:
             k, v = kv.split("=")
             op.set_option(k, int(v))
@@ -66,10 +69,28 @@ def main():
 
     if args.one:
         op, d_C = make(*args.one)
-        for _ in range(args.steps):
-            op.run(d_B, d_C)
-        torch.cuda.synchronize()
-        print(json.dumps({"one": args.one, "steps": args.steps, "n_launches": op.get_option("n_launches")}))
+        ms = timed(lambda: op.run(d_B, d_C), args.steps)
+        print(json.dumps({"one": args.one, "steps": args.steps, "n_launches": op.get_option("n_launches"), "ms": round(ms, 4)}))
+        return
+
+    if args.sweep:
+        combos = [()] + [(("block_sweep", 1), ("block_sweep_cols", c), ("block_sweep_min_tracks", t))
+                         for c, t in ((2048, 5), (1024, 5), (4096, 5), (2048, 3), (512, 4), (8192, 5))]
+        ops = {c: make(2, 4, c) for c in combos}
+        ref = ops[()][1]
+        res = {c: [] for c in combos}
+        for _ in range(args.rounds):
+            for c, (op, d_C) in ops.items():
+                res[c].append(timed(lambda: op.run(d_B, d_C)))
+        flops = 2.0 * nnz * N
+        for c, (op, d_C) in ops.items():
+            ms = float(np.median(res[c]))
+            nd, _ = count_bitdiff(d_C, ref)
+            print(json.dumps({"options": dict(c), "ms_median": round(ms, 4), "ms_min": round(min(res[c]), 4), "TFLOPs": round(flops / ms / 1e9, 2),
+                              "n_sweep_workgroups": op.get_option("n_sweep_workgroups"), "n_sweep_pieces": op.get_option("n_sweep_pieces"),
+                              "n_sweep_trips": op.get_option("n_sweep_trips"), "n_residual_items": op.get_option("n_block_residual_items"),
+                              "n_pieces": op.get_option("n_block_pieces"), "n_launches": op.get_option("n_launches"),
+                              "preprocess_us": op.get_option("preprocess_us"), "bitdiff_vs_items": nd, "nan_left": bool(torch.isnan(d_C).any())}), flush=True)
         return
 
     variants = [(2, 4), (1, 4), (2, 1), (1, 1)]
