@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--one", type=int, nargs=2, default=None)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--remap", action="store_true", help="XCD remap of the item list auto / off / on (identical configurations differ by up to 3 %% with the placement of their C buffers: read differences against that)")
     ap.add_argument("--sweep", action="store_true", help="items vs B-stationary sweeps (block_sweep; A/B library: MI_SPMM_LIB=hpc_amd/libmi_spmm_ablate.so) at several segment lengths / track floors")
     args = ap.parse_args()
     import torch
@@ -73,9 +74,14 @@ def main():
         print(json.dumps({"one": args.one, "steps": args.steps, "n_launches": op.get_option("n_launches"), "ms": round(ms, 4)}))
         return
 
-    if args.sweep:
-        combos = [()] + [(("block_sweep", 1), ("block_sweep_cols", c), ("block_sweep_min_tracks", t))
-                         for c, t in ((2048, 5), (1024, 5), (4096, 5), (2048, 3), (512, 4), (8192, 5))]
+    if args.remap or args.sweep:
+        if args.remap:
+            combos = [(), (("xcd_remap", 0),), (("xcd_remap", 1),), (("xcd_remap", -1),)]
+            extra_keys = ()
+        else:
+            combos = [()] + [(("block_sweep", 1), ("block_sweep_cols", c), ("block_sweep_min_tracks", t))
+                             for c, t in ((2048, 5), (1024, 5), (4096, 5), (2048, 3), (512, 4), (8192, 5))]
+            extra_keys = ("n_sweep_workgroups", "n_sweep_pieces", "n_sweep_trips", "n_block_residual_items")
         ops = {c: make(2, 4, c) for c in combos}
         ref = ops[()][1]
         res = {c: [] for c in combos}
@@ -86,11 +92,11 @@ def main():
         for c, (op, d_C) in ops.items():
             ms = float(np.median(res[c]))
             nd, _ = count_bitdiff(d_C, ref)
-            print(json.dumps({"options": dict(c), "ms_median": round(ms, 4), "ms_min": round(min(res[c]), 4), "TFLOPs": round(flops / ms / 1e9, 2),
-                              "n_sweep_workgroups": op.get_option("n_sweep_workgroups"), "n_sweep_pieces": op.get_option("n_sweep_pieces"),
-                              "n_sweep_trips": op.get_option("n_sweep_trips"), "n_residual_items": op.get_option("n_block_residual_items"),
-                              "n_pieces": op.get_option("n_block_pieces"), "n_launches": op.get_option("n_launches"),
-                              "preprocess_us": op.get_option("preprocess_us"), "bitdiff_vs_items": nd, "nan_left": bool(torch.isnan(d_C).any())}), flush=True)
+            line = {"options": dict(c), "ms_median": round(ms, 4), "ms_min": round(min(res[c]), 4), "TFLOPs": round(flops / ms / 1e9, 2),
+                    "n_pieces": op.get_option("n_block_pieces"), "n_launches": op.get_option("n_launches"),
+                    "preprocess_us": op.get_option("preprocess_us"), "bitdiff_vs_items": nd, "nan_left": bool(torch.isnan(d_C).any())}
+            line.update({k: op.get_option(k) for k in extra_keys})
+            print(json.dumps(line), flush=True)
         return
 
     variants = [(2, 4), (1, 4), (2, 1), (1, 1)]
