@@ -267,8 +267,7 @@ static int build_block_items(mi_spmm_handle *h)
                     continue;
                 }
                 out.emplace_back();
-                // waves hold tracks (2w, 2w+1): deal the tracks out so that every wave gets a full one before any gets two
-                for (size_t t = t0; t < t1; ++t) out.back().tr[((t - t0) % 4) * 2 + (t - t0) / 4] = std::move(tracks[t].ks);
+                for (size_t t = t0; t < t1; ++t) out.back().tr[t - t0] = std::move(tracks[t].ks);
             }
             i = j;
         }
@@ -560,7 +559,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
 #ifdef MI_SPMM_ABLATE
     h->block_sweep = 0;
     h->block_sweep_cols = 2048;
-    h->block_sweep_min_tracks = 5;
+    h->block_sweep_min_tracks = 4;
 #endif
     h->kernel = 2;
     h->gpu_preprocess = 1;

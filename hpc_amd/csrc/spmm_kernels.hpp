@@ -872,29 +872,25 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
 
 #ifdef MI_SPMM_ABLATE
 // ---- block path, B-stationary sweeps: EXPERIMENT, A/B library only (make -C hpc_amd/csrc ablate) ---------------
-// Measured on C4 (profiles/r02_c4_block_path_notes.txt): bit-identical to the items, fabric traffic of the sweep launches
-// 4.5 GB instead of 6.1 GB (B once per pass), but 1.35-2.1 ms against the items' 1.15-1.2 ms: a trip is 16 B rows =
-// at most 1.7 us of MFMA work per wave behind one workgroup barrier, and what surrounds it (table reads, DMA issue,
-// barrier skew, tile stores) is issued in order by the same wave and does not hide behind the matrix unit.  Kept out of
-// the shipped library; the design notes below are what a coarser-grained successor would start from.
-// The item kernel above gives every wave its own stretch of B: a 128-column run reaches its second half one half-item
-// after the items STARTING there have read it, and the XCD's 4 MB L2 has turned over several times by then -- B
-// crosses the fabric ~1.7 times per pass.  Here the column axis is cut into long segments and the run pieces that
-// start in a segment are laid on TRACKS (interval partitioning on the host: a track's pieces are disjoint and
-// ascending).  A workgroup sweeps its segment once, in trips of 16 columns = 16 B rows:
-//   * the 16 rows of a trip are brought into LDS ONCE per workgroup (LDS-DMA, a 3-stage ring: trips t+1 and t+2 are
-//     in flight while t is computed; one workgroup barrier per trip) and feed all 8 tracks: 4 waves x 2 accumulator
-//     sets, each track a 16-row group's 16 x 256 tile;
-//   * a track's A operands (16 rows x 16 values per trip) ride the same ring, wave-private;
+// The item kernel gives every wave its own stretch of B: a 128-column run reaches its second half one half-item after
+// the items STARTING there have read it, and the XCD's 4 MB L2 has turned over several times by then -- B crosses the
+// fabric ~1.7 times per pass.  Here the column axis is cut into long segments and the run pieces that start in a
+// segment are laid on 8 TRACKS (interval partitioning on the host: a track's pieces are disjoint and ascending).
+// A wave sweeps the segment once, in trips of 16 columns = 16 B rows, for ALL 8 tracks but only for a 64-column
+// quarter of the 256-column slab (the 4 waves of a workgroup take the 4 quarters): 8 accumulator sets of 4 tiles.
+//   * every B register feeds up to 8 MFMAs, and every consumer of a B row in the segment is the SAME wave: B crosses
+//     the fabric once per pass by construction, with no LDS, no barrier and no timing assumption;
+//   * the A operands of the 8 tracks (16 x 16 values per trip and track) are read by each of the 4 quarter-waves
+//     (the same lines a few hundred cycles apart: L2 hits);
 //   * what each track does in each trip -- nothing, multiply, start a piece (from +0 or from the tile an earlier pass
 //     carried), end one (store the tile) -- is a table the host wrote (SweepEnt): the kernel keeps no piece state.
-// Every consumer of a B row inside the segment meets it at the same time; the arithmetic per output element is
-// untouched (same k order, same MFMA chain as spmm_block_items).  256-column slabs only.
+// The arithmetic per output element is untouched (same k order, same MFMA chain as spmm_block_items).
 //
-// Carried tiles between two sweep passes are kept in C's own tile region as a REGISTER IMAGE: row t of the tile holds
-// accumulator tile t, lane l's four registers at columns 4l..4l+3 -- 16 coalesced 16-byte accesses each way, no 4x4
-// register shuffle.  The host only lets a group into the sweeps when all of its pieces are (plan_types.hpp), so no
-// other kernel ever sees that layout, and the group's last pass overwrites it with the real rows.
+// Carried tiles between two sweep passes are kept in C's own tile region as a REGISTER IMAGE (accumulator tile tl of
+// the quarter at rows 4 tl + kq): no 4x4 register shuffle.  The host only lets a group into the sweeps when all of its
+// pieces are, so no other kernel ever sees that layout, and the group's last pass overwrites it with the real rows.
+// (First design, profiles/r02_c4_block_path_notes.txt: 2 tracks per wave over the full slab, B through an LDS-DMA ring
+// with a workgroup barrier per trip -- right traffic, 1.35-2.1 ms: too little matrix work per barrier.)
 struct SweepArgs {
     const SweepWG *wgs;
     const int32_t *cols;       // [trip]: first B row of the trip
@@ -908,196 +904,125 @@ struct SweepArgs {
     int32_t remap;
 };
 
-// One wave-instruction of LDS-DMA: lane l's 16 bytes at sbase + voff land at lds_dst + 16 l (M0 carries the LDS address;
-// saved and restored inside the statement, cdna_hip_programming.md 'What hipcc does not do').  hipcc does not count it in
-// its s_waitcnt bookkeeping: the waits are the kernel's own (kSweepLoadsPerTrip).
-__device__ __forceinline__ void glds16(uint32_t lds_dst, const void *sbase, uint32_t voff)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-
-constexpr int kSweepLoadsPerTrip = 6;   // per wave and trip: 2 A tiles (its tracks) + 4 of the 16 B rows
-
-// The trip tables are read through the scalar cache (wave-uniform addresses in the constant address space -> s_load):
-// a vector load would sit in the same counter as the LDS-DMA, and its wait would drain the ring.
-typedef int int8v __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(4))) int8v *SweepEntPairPtr;    // two adjacent SweepEnt
-typedef const __attribute__((address_space(4))) int32_t *SweepColPtr;
+typedef int int4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) int32_t *SweepColPtr;     // wave-uniform reads through the scalar cache
 
 __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_sweep(SweepArgs a)
 {
-    constexpr int XC = 4, V = 4, TILES = 16, CW = 64, NS = 256;
+    constexpr int TR = kSweepTracks, QT = 4;   // tracks per wave; 16-column tiles per quarter
     typedef float4v BV;
-    __shared__ BV Bst[kSweepStages][kSweepTrip][64];      // 48 KB: stage, B row of the trip, 256 columns
-    __shared__ BV Ast[kSweepStages][kSweepTracks][64];    // 24 KB: stage, track, lane image (row i16, values 4kq..4kq+3)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vblk = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    if (vblk >= a.n_wgs) return;          // workgroup-uniform: nobody is left waiting at a barrier
+    if (vblk >= a.n_wgs) return;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int slab0 = (int)blockIdx.y * NS;
+    const int colv = (int)blockIdx.y * 256 + 64 * wave + 4 * i16;     // this lane's 4 columns: tile e = column colv + e ... of 16-lane rows
     const SweepColPtr wrec = (SweepColPtr)reinterpret_cast<const int32_t *>(a.wgs + vblk);
     const int trip_begin = wrec[0], T = wrec[1];
     const SweepColPtr cols = (SweepColPtr)(a.cols + trip_begin);
-    const SweepEntPairPtr ents = (SweepEntPairPtr)(a.ents + (int64_t)trip_begin * kSweepTracks + 2 * wave);   // this wave's two tracks: [trip * 4]
-    const uint32_t lds_b = (uint32_t)(size_t)&Bst[0][0][0], lds_a = (uint32_t)(size_t)&Ast[0][0][0];
-    const uint32_t b_voff = (uint32_t)(slab0 + 4 * lane) * 4u;
+    const int4i *ents = reinterpret_cast<const int4i *>(a.ents) + (int64_t)trip_begin * TR + ((lane & 7) < TR ? (lane & 7) : TR - 1);   // lane l < TR keeps track l's entry
 
-    // What the tables say about trip u (its B rows, this wave's two tracks), clamped reads past the end: never used.
-    struct Trip { int col; int8v ep; };
-    auto table = [&](int u) {
-        Trip q;
-        const int uc = u < T ? u : T - 1;
-        q.col = cols[uc];
-        q.ep = ents[(int64_t)uc * (kSweepTracks / 2)];     // {group, flags, a_off, row_len} x 2
-        return q;
+    // A trip's operands: B rows 4s + kq (this lane's 4 columns) and, per track, A values 4kq..4kq+3 of row i16.
+    // Every B row is read by this wave and nobody else, i.e. always from HBM: its loads run kSweepAhead trips ahead
+    // (a trip of a sparsely occupied wave is short); the A lines are shared with the other three quarter-waves.
+    constexpr int AH = kSweepAhead;
+    struct BOps { BV b[4]; };
+    struct AOps { float4v araw[TR]; };
+    auto table = [&](int u) { return ents[(int64_t)(u < T ? u : T - 1) * TR]; };
+    auto column = [&](int u) { return cols[u < T ? u : T - 1]; };
+    auto fetch_b = [&](BOps &P, int col) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) P.b[s4] = *reinterpret_cast<const BV *>(a.B + (int64_t)(col + 4 * s4 + kq) * a.ldb + colv);
     };
-    auto issue = [&](const Trip &q, int stage) {  // a trip's operands -> ring stage (kSweepLoadsPerTrip wave-instructions)
-        glds16(lds_a + (uint32_t)((stage * kSweepTracks + 2 * wave) * 1024), a.vals + q.ep[2], (uint32_t)(i16 * q.ep[3] + 4 * kq) * 4u);
-        glds16(lds_a + (uint32_t)((stage * kSweepTracks + 2 * wave + 1) * 1024), a.vals + q.ep[6], (uint32_t)(i16 * q.ep[7] + 4 * kq) * 4u);
+    auto fetch_a = [&](AOps &P, const int4i &E) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            glds16(lds_b + (uint32_t)((stage * kSweepTrip + 4 * wave + r) * 1024), a.B + (int64_t)(q.col + 4 * wave + r) * a.ldb, b_voff);
-    };
-    // vector-memory operations complete in issue order, stores included (MI355X_MICROARCH.md): "all but the n youngest"
-    auto wait_vm = [&](int n) {
-        if (n == kSweepLoadsPerTrip) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kSweepLoadsPerTrip) : "memory");
-        else if (n == 2 * kSweepLoadsPerTrip) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * kSweepLoadsPerTrip) : "memory");
-        else if (n == kSweepLoadsPerTrip + TILES) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kSweepLoadsPerTrip + TILES) : "memory");
-        else if (n == kSweepLoadsPerTrip + 2 * TILES) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kSweepLoadsPerTrip + 2 * TILES) : "memory");
-        else if (n == TILES) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(TILES) : "memory");
-        else if (n == 2 * TILES) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * TILES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    float4a acc[2][TILES];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) acc[j][t] = (float4a){0.f, 0.f, 0.f, 0.f};
-    BV R0[2][XC], R1[2][XC];              // B operands of the trip's rows 0..7 / 8..15: tile (x, e) = columns 64x + 4 i16 + e of row 4s + kq
-    float af[2][4];                       // A operands: track j, k = 4s + kq of row i16
-    auto read_b = [&](BV (&R)[2][XC], int stage, int half) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int x = 0; x < XC; ++x) R[s2][x] = Bst[stage][8 * half + 4 * s2 + kq][16 * x + i16];
-    };
-    auto read_a = [&](int stage) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float *ap = reinterpret_cast<const float *>(&Ast[stage][2 * wave + j][0]);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) af[j][s4] = ap[(i16 + 16 * s4) * 4 + kq];
-        }
-    };
-    auto mfma_half = [&](const BV (&R)[2][XC], int half, const bool (&on)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (on[j]) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int x = 0; x < XC; ++x)
-#pragma unroll
-                        for (int el = 0; el < V; ++el)
-                            acc[j][V * x + el] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][2 * half + s2], R[s2][x][el], acc[j][V * x + el], 0, 0, 0);
-            }
+        for (int j = 0; j < TR; ++j) {
+            const int a_off = __builtin_amdgcn_readlane(E[2], j), rl = __builtin_amdgcn_readlane(E[3], j);   // idle track: 0, 0 (any valid address)
+            P.araw[j] = Vec<4>::load(a.vals + a_off + i16 * rl + 4 * kq);
         }
     };
 
-    // ---- prologue: the ring's three stages are free -- trips 0, 1, 2 go out at once; the tables run ahead in SGPRs
-    Trip q0 = table(0), q1 = table(1), q2 = table(2), q3 = table(3);    // q_k: trip t + k
-    issue(q0, 0);
-    if (T > 1) issue(q1, 1);
-    if (T > 2) issue(q2, 2);
-    wait_vm((T > 2 ? 2 : T > 1 ? 1 : 0) * kSweepLoadsPerTrip);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_b(R0, 0, 0);
-    read_b(R1, 0, 1);
-    read_a(0);
-    int st = 0, n_stored = 0;             // st = t % 3; n_stored: tile stores this wave issued at the end of the previous trip
-    for (int t = 0; t < T; ++t) {
-        const SweepEnt e[2] = {{q0.ep[0], q0.ep[1], q0.ep[2], q0.ep[3]}, {q0.ep[4], q0.ep[5], q0.ep[6], q0.ep[7]}};
-        const bool on[2] = {e[0].group >= 0, e[1].group >= 0};
-        const int st1 = st == 2 ? 0 : st + 1;
-        // pieces that start here: +0, or the register image an earlier pass left in C
+    float4a acc[TR][QT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (on[j] && (e[j].flags & kSweepFirst)) {
-                if (e[j].flags & kSweepCarryIn) {
-                    const float *cp = a.C + (int64_t)(e[j].group << 4) * a.ldc + slab0 + 4 * lane;
+    for (int j = 0; j < TR; ++j)
 #pragma unroll
-                    for (int tl = 0; tl < TILES; ++tl) acc[j][tl] = *reinterpret_cast<const float4a *>(cp + (int64_t)tl * a.ldc);
+        for (int e = 0; e < QT; ++e) acc[j][e] = (float4a){0.f, 0.f, 0.f, 0.f};
+
+    // one trip: pieces that start (before the loads go out: a wait for a carried tile must not drain them), the loads
+    // for later trips, then per busy track the 16 MFMAs of the trip and, where its piece ends, the tile store
+    BOps Bq[AH + 1];                      // Bq[k]: trip t + k
+    auto trip = [&](const AOps &P, AOps &Pn, const int4i &E, const int4i &En, int col_far) {
 #pragma unroll
-                    for (int tl = 0; tl < TILES; ++tl) asm volatile("" : "+v"(acc[j][tl]));   // arrived, as far as hipcc's bookkeeping goes
+        for (int j = 0; j < TR; ++j) {
+            const int grp = __builtin_amdgcn_readlane(E[0], j), fl = __builtin_amdgcn_readlane(E[1], j);
+            if (grp >= 0 && (fl & kSweepFirst)) {
+                if (fl & kSweepCarryIn) {
+                    const float *cp = a.C + (int64_t)((grp << 4) + kq) * a.ldc + colv;
+#pragma unroll
+                    for (int tl = 0; tl < QT; ++tl) acc[j][tl] = *reinterpret_cast<const float4a *>(cp + (int64_t)(4 * tl) * a.ldc);
                 } else {
 #pragma unroll
-                    for (int tl = 0; tl < TILES; ++tl) acc[j][tl] = (float4a){0.f, 0.f, 0.f, 0.f};
+                    for (int tl = 0; tl < QT; ++tl) acc[j][tl] = (float4a){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_half(R0, 0, on);
+        fetch_b(Bq[AH], col_far);
+        fetch_a(Pn, En);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- behind those MFMAs: trip t+1 becomes readable, trip t+3 goes out, the tables move on.
-        // Every LDS read of stage t % 3 has returned (the wait), for every wave (the barrier): trip t+3 may overwrite it.
-        // Younger than trip t+1's DMA: trip t+2's (if any) and the tile stores of trip t-1's ending pieces.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const Trip q4 = table(t + 4);
-        if (t + 1 < T) {
-            wait_vm((t + 2 < T ? kSweepLoadsPerTrip : 0) + n_stored);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + 3 < T) issue(q3, st);
-            read_b(R0, st1, 0);
-        }
-        n_stored = 0;
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(R1, 1, on);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) {
-            read_b(R1, st1, 1);
-            read_a(st1);
-        }
-        // pieces that end here
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (on[j] && (e[j].flags & kSweepLast)) {
-                const int r0 = e[j].group << 4;
-                n_stored += TILES;
-                if (e[j].flags & kSweepCarryOut) {       // register image, for the next pass's sweep
-                    float *cp = a.C + (int64_t)r0 * a.ldc + slab0 + 4 * lane;
+        for (int j = 0; j < TR; ++j) {
+            const int grp = __builtin_amdgcn_readlane(E[0], j), fl = __builtin_amdgcn_readlane(E[1], j);
+            if (grp >= 0) {
+                // 4x4 transpose across the kq rows of the wave: lane (i16, kq) gets a[row i16][k = 4s + kq], s = 0..3
+                const unsigned v0 = __float_as_uint(P.araw[j][0]), v1 = __float_as_uint(P.araw[j][1]);
+                const unsigned v2 = __float_as_uint(P.araw[j][2]), v3 = __float_as_uint(P.araw[j][3]);
+                const auto r02 = __builtin_amdgcn_permlane32_swap(v0, v2, false, false);
+                const auto r13 = __builtin_amdgcn_permlane32_swap(v1, v3, false, false);
+                const auto s01 = __builtin_amdgcn_permlane16_swap(r02[0], r13[0], false, false);
+                const auto s23 = __builtin_amdgcn_permlane16_swap(r02[1], r13[1], false, false);
+                const float af[4] = {__uint_as_float(s01[0]), __uint_as_float(s01[1]), __uint_as_float(s23[0]), __uint_as_float(s23[1])};
 #pragma unroll
-                    for (int tl = 0; tl < TILES; ++tl) *reinterpret_cast<float4a *>(cp + (int64_t)tl * a.ldc) = acc[j][tl];
-                } else {                                  // register q of the tiles (x, 0..3) is the float4 C[r0 + 4kq + q][64x + 4 i16 ..]
+                for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float *cp = a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + slab0 + V * i16;
+                    for (int e = 0; e < QT; ++e)
+                        acc[j][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], Bq[0].b[s4][e], acc[j][e], 0, 0, 0);
+                if (fl & kSweepLast) {
+                    const int r0 = grp << 4;
+                    if (fl & kSweepCarryOut) {           // register image, for the next pass's sweep
+                        float *cp = a.C + (int64_t)(r0 + kq) * a.ldc + colv;
 #pragma unroll
-                        for (int x = 0; x < XC; ++x) {
+                        for (int tl = 0; tl < QT; ++tl) *reinterpret_cast<float4a *>(cp + (int64_t)(4 * tl) * a.ldc) = acc[j][tl];
+                    } else {                              // register q of the tiles 0..3 is the float4 C[r0 + 4kq + q][colv ..]
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
                             BV v;
 #pragma unroll
-                            for (int el = 0; el < V; ++el) v[el] = acc[j][V * x + el][q];
-                            __builtin_nontemporal_store(v, reinterpret_cast<BV *>(cp + CW * x));
+                            for (int e = 0; e < QT; ++e) v[e] = acc[j][e][q];
+                            __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + colv));
                         }
                     }
                 }
             }
         }
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
-        q3 = q4;
-        st = st1;
+#pragma unroll
+        for (int k = 0; k < AH; ++k) Bq[k] = Bq[k + 1];
+    };
+
+    AOps P0, P1;
+    int4i E0 = table(0), E1 = table(1);
+#pragma unroll
+    for (int k = 0; k < AH; ++k) fetch_b(Bq[k], column(k));
+    fetch_a(P0, E0);
+    for (int t = 0; t < T; t += 2) {
+        const int4i E2 = table(t + 2);
+        const int c1 = column(t + AH), c2 = column(t + AH + 1);
+        trip(P0, P1, E0, E1, c1);
+        if (t + 1 < T) trip(P1, P0, E1, E2, c2);
+        E0 = E2;
+        E1 = table(t + 3);
     }
 }
-
 #endif  // MI_SPMM_ABLATE (sweeps)
 
 // Cuts a qualifying group's column list (the list of its first row) into runs of consecutive columns.

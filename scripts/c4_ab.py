@@ -80,7 +80,7 @@ def main():
             extra_keys = ()
         else:
             combos = [()] + [(("block_sweep", 1), ("block_sweep_cols", c), ("block_sweep_min_tracks", t))
-                             for c, t in ((2048, 5), (1024, 5), (4096, 5), (2048, 3), (512, 4), (8192, 5))]
+                             for c, t in ((2048, 4), (1024, 4), (4096, 4), (2048, 2), (512, 3), (8192, 4), (256, 3))]
             extra_keys = ("n_sweep_workgroups", "n_sweep_pieces", "n_sweep_trips", "n_block_residual_items")
         ops = {c: make(2, 4, c) for c in combos}
         ref = ops[()][1]

@@ -479,7 +479,7 @@ def test_block_path_shared_runs_and_passes(device, oracle, N):
 
 
 @pytest.mark.parametrize("N,seg_cols,min_tracks,slots,min_gap", [(256, 1024, 1, 12, 0), (256, 256, 3, 12, 0), (512, 64, 1, 24, 0), (256, 4096, 5, 6, 0), (768, 512, 2, 24, 0),
-                                                                 (256, 1024, 4, 90, 4), (256, 512, 1, 90, 4), (512, 2048, 8, 46, 2)])
+                                                                 (256, 1024, 4, 90, 4), (256, 512, 1, 90, 4), (512, 2048, 6, 46, 2)])
 def test_block_sweeps_bitwise(device, oracle, N, seg_cols, min_tracks, slots, min_gap):
     """EXPERIMENT, A/B library only (make -C hpc_amd/csrc ablate; MI_SPMM_LIB=hpc_amd/libmi_spmm_ablate.so pytest -k block_sweeps):
     B-stationary sweeps ("block_sweep" = 1).  Run pieces whose first column and length are multiples of 16 ride on tracks
@@ -502,7 +502,7 @@ def test_block_sweeps_bitwise(device, oracle, N, seg_cols, min_tracks, slots, mi
     ref = oracle.spmm_omp(ptr, idx, vals, B)
     opts = {"long_row_threshold": 2048, "block_sweep": 1, "block_sweep_cols": seg_cols, "block_sweep_min_tracks": min_tracks}
     C, op = run_spmm(device, ptr, idx, vals, B, options=opts)
-    assert op.get_option("n_sweep_workgroups") > 0 and op.get_option("n_sweep_pieces") > (30 if min_tracks == 8 else 100)
+    assert op.get_option("n_sweep_workgroups") > 0 and op.get_option("n_sweep_pieces") > (30 if min_tracks >= 6 else 100)
     assert op.get_option("n_block_residual_items") > 0
     assert op.get_option("n_sweep_pieces") < op.get_option("n_block_pieces")
     assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).any(axis=1).sum()} rows differ"
