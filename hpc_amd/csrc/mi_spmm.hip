@@ -174,7 +174,7 @@ static int build_block_items(mi_spmm_handle *h)
     std::vector<BlockItem> items;
     int64_t n_pieces = 0;
     int32_t n_pass = 0, n_shared = 0;
-    std::vector<Key> keys, rest;
+    std::vector<Key> keys;
     std::vector<BlockItem> lists, singles, shared;
 
     auto piece_of = [&](const Key &k) {
