@@ -440,8 +440,8 @@ def main():
             tf = flops_total / (dev_ms_mean * 1e-3) / 1e12
             blk_bytes = 4 * nnz + 4 * nnz // 16 + 4 * n_loc * nnz // 16 + 4 * M * n_loc
             roof = {"bound": "mfma", "kernel": "mi::spmm_block_items (v_mfma_f32_16x16x4_f32)", "achieved": round(tf, 2), "peak": 157.3,
-                    "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel_ms": round(dev_ms_mean, 4), "launches_per_step": op.get_option("n_launches"),
+                    "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": traffic, "traffic_per": "step (all launches of the block kernels)",
+                    "traffic_source": traffic_source, "kernel_ms": round(dev_ms_mean, 4), "launches_per_step": op.get_option("n_launches"),
                     "bytes_min_per_step": model["bytes_min"], "bytes_block_reuse_model_per_step": int(blk_bytes),
                     "bytes_gather_model_per_step": model["bytes_alg"],
                     "GBs_on_bytes_min": round(model["bytes_min"] / (dev_ms_mean * 1e-3) / 1e9, 1),
