@@ -308,8 +308,8 @@ static int build_block_items(mi_spmm_handle *h)
     if (items.empty()) return MI_SPMM_OK;
 
 #ifdef MI_SPMM_ABLATE
-    // The second plan, used by full-row-range steps: sweeps + the items of everything the sweeps do not take.  A group
-    // rides the sweeps with ALL of its pieces or with none (carried tiles between sweep passes are register images).
+    // The second plan, used by full-row-range steps: sweeps + the items of everything the sweeps do not take (carried
+    // tiles have one layout, C's own: a group's pieces may ride the sweeps in one pass and be items in another).
     std::vector<SweepWG> wgs;
     std::vector<int32_t> trip_cols;
     std::vector<SweepEnt> ents;
@@ -317,7 +317,6 @@ static int build_block_items(mi_spmm_handle *h)
     if (sweeping) {
         std::vector<std::vector<WGPlan>> plans((size_t)n_pass);
         std::vector<std::vector<Key>> rests((size_t)n_pass);
-        std::vector<uint8_t> riding((size_t)ng, 0);
         for (int pass = 0; pass < n_pass; ++pass) {
             std::vector<Key> sw;
             for (const Key &k : pass_keys[(size_t)pass]) {
@@ -325,26 +324,14 @@ static int build_block_items(mi_spmm_handle *h)
                 (ok ? sw : rests[(size_t)pass]).push_back(k);
             }
             form_sweeps(sw, rests[(size_t)pass], plans[(size_t)pass]);
-            for (const WGPlan &w : plans[(size_t)pass])
-                for (const auto &tr : w.tr)
-                    for (const Key &k : tr) riding[(size_t)k.gi] |= (uint8_t)(1u << k.ord);
         }
-        for (int32_t gi = 0; gi < ng; ++gi)         // all or nothing
-            if (riding[(size_t)gi] != (uint8_t)((1u << gp[(size_t)gi].n) - 1u)) riding[(size_t)gi] = 0;
         std::vector<std::pair<int32_t, int32_t>> iv;
         for (int pass = 0; pass < n_pass; ++pass) {
             h->sweep_launch[pass].off = (int32_t)wgs.size();
             for (WGPlan &w : plans[(size_t)pass]) {
                 iv.clear();
-                for (auto &tr : w.tr) {
-                    size_t keep = 0;
-                    for (const Key &k : tr) {
-                        if (riding[(size_t)k.gi]) tr[keep++] = k;
-                        else rests[(size_t)pass].push_back(k);
-                    }
-                    tr.resize(keep);
+                for (const auto &tr : w.tr)
                     for (const Key &k : tr) iv.emplace_back(k.col, k.col + k.len);
-                }
                 if (iv.empty()) continue;
                 std::sort(iv.begin(), iv.end());
                 SweepWG rec;

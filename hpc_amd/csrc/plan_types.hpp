@@ -64,7 +64,7 @@ constexpr int kSweepAhead = 3;    // trips the B loads run ahead of the MFMAs (r
 constexpr int kSweepTrip = 16;    // columns (B rows) per trip; sweepable pieces start and end on multiples of it
 
 constexpr int kSweepFirst = 1;    // the piece's first trip: accumulators start from +0 or from the carried tile
-constexpr int kSweepLast = 2;     // its last trip: the tile leaves (C, or the carried-tile image for the next pass)
+constexpr int kSweepLast = 2;     // its last trip: the tile is stored (final rows, or the chain a later pass continues)
 constexpr int kSweepCarryIn = 4;
 constexpr int kSweepCarryOut = 8;
 

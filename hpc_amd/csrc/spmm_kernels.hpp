@@ -886,9 +886,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
 //     carried), end one (store the tile) -- is a table the host wrote (SweepEnt): the kernel keeps no piece state.
 // The arithmetic per output element is untouched (same k order, same MFMA chain as spmm_block_items).
 //
-// Carried tiles between two sweep passes are kept in C's own tile region as a REGISTER IMAGE (accumulator tile tl of
-// the quarter at rows 4 tl + kq): no 4x4 register shuffle.  The host only lets a group into the sweeps when all of its
-// pieces are, so no other kernel ever sees that layout, and the group's last pass overwrites it with the real rows.
+// Carried tiles have the layout of C itself (as in spmm_block_items): a group's pieces may ride the sweeps in one pass and
+// be items in another.
 // (First design, profiles/r02_c4_block_path_notes.txt: 2 tracks per wave over the full slab, B through an LDS-DMA ring
 // with a workgroup barrier per trip -- right traffic, 1.35-2.1 ms: too little matrix work per barrier.)
 struct SweepArgs {
@@ -956,10 +955,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_sweep(SweepArgs a
         for (int j = 0; j < TR; ++j) {
             const int grp = __builtin_amdgcn_readlane(E[0], j), fl = __builtin_amdgcn_readlane(E[1], j);
             if (grp >= 0 && (fl & kSweepFirst)) {
-                if (fl & kSweepCarryIn) {
-                    const float *cp = a.C + (int64_t)((grp << 4) + kq) * a.ldc + colv;
+                if (fl & kSweepCarryIn) {                // the chain an earlier pass (sweep or item) left in C: row r0 + 4kq + q holds register q of tiles 0..3
+                    const float *cp = a.C + (int64_t)((grp << 4) + 4 * kq) * a.ldc + colv;
+                    BV t4[4];
 #pragma unroll
-                    for (int tl = 0; tl < QT; ++tl) acc[j][tl] = *reinterpret_cast<const float4a *>(cp + (int64_t)(4 * tl) * a.ldc);
+                    for (int q = 0; q < 4; ++q) t4[q] = *reinterpret_cast<const BV *>(cp + (int64_t)q * a.ldc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < QT; ++e) acc[j][e][q] = t4[q][e];
                 } else {
 #pragma unroll
                     for (int tl = 0; tl < QT; ++tl) acc[j][tl] = (float4a){0.f, 0.f, 0.f, 0.f};
@@ -989,18 +993,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_sweep(SweepArgs a
                         acc[j][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], Bq[0].b[s4][e], acc[j][e], 0, 0, 0);
                 if (fl & kSweepLast) {
                     const int r0 = grp << 4;
-                    if (fl & kSweepCarryOut) {           // register image, for the next pass's sweep
-                        float *cp = a.C + (int64_t)(r0 + kq) * a.ldc + colv;
+                    // register q of the tiles 0..3 is the float4 C[r0 + 4kq + q][colv ..]; a tile a later pass continues stays cacheable
 #pragma unroll
-                        for (int tl = 0; tl < QT; ++tl) *reinterpret_cast<float4a *>(cp + (int64_t)(4 * tl) * a.ldc) = acc[j][tl];
-                    } else {                              // register q of the tiles 0..3 is the float4 C[r0 + 4kq + q][colv ..]
+                    for (int q = 0; q < 4; ++q) {
+                        BV v;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            BV v;
-#pragma unroll
-                            for (int e = 0; e < QT; ++e) v[e] = acc[j][e][q];
-                            __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + colv));
-                        }
+                        for (int e = 0; e < QT; ++e) v[e] = acc[j][e][q];
+                        BV *dst = reinterpret_cast<BV *>(a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + colv);
+                        if (fl & kSweepCarryOut) *dst = v;
+                        else __builtin_nontemporal_store(v, dst);
                     }
                 }
             }

@@ -484,7 +484,7 @@ def test_block_sweeps_bitwise(device, oracle, N, seg_cols, min_tracks, slots, mi
     """EXPERIMENT, A/B library only (make -C hpc_amd/csrc ablate; MI_SPMM_LIB=hpc_amd/libmi_spmm_ablate.so pytest -k block_sweeps):
     B-stationary sweeps ("block_sweep" = 1).  Run pieces whose first column and length are multiples of 16 ride on tracks
     (they start from zero or carried accumulators and leave with a tile store, workgroups skip the gaps between their
-    spans), everything else -- odd lengths, lists, groups with any such piece, tracks too few for a workgroup -- stays
+    spans), everything else -- odd lengths, lists, tracks too few for a workgroup -- stays
     items.  Same bits as the oracle and as the item-only plan; a row-range step falls back to the items.  The shipped
     library has no such option (test_product_library_refuses_ablation_options): skipped there."""
     import torch
