@@ -9,9 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MI_SPMM_LIB: scripts/ may point at the A/B build (hpc_amd/libmi_spmm_ablate.so, `make -C hpc_amd/csrc ablate`);
-# tests and bench.py never set it.
-LIB_PATH = os.environ.get("MI_SPMM_LIB") or os.path.join(_HERE, "libmi_spmm.so")
+# Exactly one library is ever loaded: the in-tree product build (no environment override).
+LIB_PATH = os.path.join(_HERE, "libmi_spmm.so")
 
 # name -> (restype, argtypes); kept in the order of include/mi_spmm.h.
 # tests/test_abi_symbols.py parses the header and checks this table covers it.

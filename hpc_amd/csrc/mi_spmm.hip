@@ -39,7 +39,7 @@ struct mi_spmm_handle {
     int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
     int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
-    int64_t kernel;  // 1 = spmm_rows (per-row fetch), 2 = spmm_rows_v2 (pipelined items)
+    int64_t kernel;  // 2 = spmm_rows_v2 (pipelined items); 1 named the first-generation kernel, retired in round 3
     int64_t split_cols;  // 1 (default): columns past the last full 256-column tile get their own launches
     int64_t segment_unroll;  // B-row gathers in flight per lane group in the segment kernel: 8, 16 or 32 (default)
     int64_t tile_cols;       // widest column tile of the rows/segment kernels: 256 (whole wave on a row), 128, 64, 32; 0 = auto
@@ -66,26 +66,12 @@ struct mi_spmm_handle {
     int64_t block_share;       // most pieces per item (1 = no sharing; default 2)
     int64_t block_max_pieces;  // most pieces a group's list is cut into = most passes (1 = never cut)
     int64_t block_run_min;     // shortest run worth a piece of its own
-    int64_t block_merge_unsafe; // A/B library only: all passes in ONE launch, dependencies ignored (timing experiment, wrong C)
     BlockItem *d_blk_items;
     int32_t n_blk_items, n_blk_pieces, n_blk_passes, n_blk_shared_items;
     // preprocess temporaries (grow-only, kept across preprocess calls, released by destroy)
     Scratch scratch_a, scratch_b;
     unsigned int *d_col_bad;   // 256 bytes: the column-range flag
     struct { int32_t off, n; } blk_launch[kMaxPieces][3];   // [pass][0: list items, 1: run items of one piece, 2: shared run items]
-#ifdef MI_SPMM_ABLATE
-    // EXPERIMENT (A/B library): B-stationary sweeps (spmm_block_sweep) -- the run pieces laid on tracks, and the items of what is left over
-    int64_t block_sweep;            // 1: full-row-range steps on 256-column slabs sweep; 0: items only
-    int64_t block_sweep_cols;       // segment length in columns (pieces STARTING in a segment share its workgroups)
-    int64_t block_sweep_min_tracks; // a workgroup with fewer tracks is not worth its B loads: those pieces stay items
-    SweepWG *d_sweep_wgs;
-    int32_t *d_sweep_cols;
-    SweepEnt *d_sweep_ents;
-    BlockItem *d_blk_res_items;
-    int32_t n_sweep_wgs, n_sweep_pieces, n_sweep_trips, n_blk_res_items;
-    struct { int32_t off, n; } sweep_launch[kMaxPieces];
-    struct { int32_t off, n; } blk_res_launch[kMaxPieces][3];
-#endif
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
@@ -106,19 +92,6 @@ static void free_plan(mi_spmm_handle *h)
     h->d_blk_items = nullptr;
     h->n_blk_items = h->n_blk_pieces = h->n_blk_passes = h->n_blk_shared_items = 0;
     std::memset(h->blk_launch, 0, sizeof(h->blk_launch));
-#ifdef MI_SPMM_ABLATE
-    if (h->d_sweep_wgs) (void)hipFree(h->d_sweep_wgs);
-    if (h->d_sweep_cols) (void)hipFree(h->d_sweep_cols);
-    if (h->d_sweep_ents) (void)hipFree(h->d_sweep_ents);
-    if (h->d_blk_res_items) (void)hipFree(h->d_blk_res_items);
-    h->d_sweep_wgs = nullptr;
-    h->d_sweep_cols = nullptr;
-    h->d_sweep_ents = nullptr;
-    h->d_blk_res_items = nullptr;
-    h->n_sweep_wgs = h->n_sweep_pieces = h->n_sweep_trips = h->n_blk_res_items = 0;
-    std::memset(h->sweep_launch, 0, sizeof(h->sweep_launch));
-    std::memset(h->blk_res_launch, 0, sizeof(h->blk_res_launch));
-#endif
     h->d_blk_flag = nullptr;
     h->d_blk_groups = nullptr;
     h->n_blk_groups = 0;
@@ -164,10 +137,6 @@ static int build_block_items(mi_spmm_handle *h)
     // the run kernels sweep whole trips (two k batches: 16 / 32 / 64 rows for 256- / 128- / narrower slabs) and fetch their A
     // operands 16 bytes at a time; a run of any other length goes through the list kernel (general lengths, dword A loads)
     const int run_unit = slab_w == 256 ? 16 : slab_w == 128 ? 32 : 64;
-#ifdef MI_SPMM_ABLATE
-    const bool sweeping = h->block_sweep != 0 && slab_w == 256 && !h->block_merge_unsafe;   // experiment: spmm_block_sweep
-    const int32_t seg_cols = (int32_t)h->block_sweep_cols;
-#endif
 
     struct Key { int32_t col, len, gi, ord; bool shareable, run; };
     struct Launch { int32_t off, n; };
@@ -226,65 +195,12 @@ static int build_block_items(mi_spmm_handle *h)
             out.insert(out.end(), cls[c]->begin(), cls[c]->end());
         }
     };
-#ifdef MI_SPMM_ABLATE
-    // The sweepable keys of one pass -> tracks -> workgroups.  Pieces are taken in (first column, longest first) order; the
-    // ones starting in the same segment of seg_cols columns are interval-partitioned: a piece goes on the track that ended
-    // last at or before its first column (best fit), or opens a new one.  kSweepTracks tracks make a workgroup; a
-    // segment's last few tracks, too few to pay for a workgroup's B loads, hand their pieces back (-> items).
-    struct Track { int32_t end; int64_t cols; std::vector<Key> ks; };
-    struct WGPlan { std::vector<Key> tr[kSweepTracks]; };
-    std::vector<Track> tracks;
-    auto form_sweeps = [&](std::vector<Key> &ks, std::vector<Key> &back, std::vector<WGPlan> &out) {
-        std::sort(ks.begin(), ks.end(), [](const Key &x, const Key &y) {
-            if (x.col != y.col) return x.col < y.col;
-            if (x.len != y.len) return x.len > y.len;
-            return x.gi < y.gi;
-        });
-        size_t i = 0;
-        while (i < ks.size()) {
-            const int32_t seg = ks[i].col / seg_cols;
-            size_t j = i;
-            tracks.clear();
-            for (; j < ks.size() && ks[j].col / seg_cols == seg; ++j) {
-                int best = -1;
-                for (size_t t = 0; t < tracks.size(); ++t)
-                    if (tracks[t].end <= ks[j].col && (best < 0 || tracks[t].end > tracks[(size_t)best].end)) best = (int)t;
-                if (best < 0) {
-                    tracks.emplace_back();
-                    best = (int)tracks.size() - 1;
-                    tracks[(size_t)best].cols = 0;
-                }
-                tracks[(size_t)best].end = ks[j].col + ks[j].len;
-                tracks[(size_t)best].cols += ks[j].len;
-                tracks[(size_t)best].ks.push_back(ks[j]);
-            }
-            // fullest tracks first, so that the workgroup that may be dropped holds the least
-            std::stable_sort(tracks.begin(), tracks.end(), [](const Track &x, const Track &y) { return x.cols > y.cols; });
-            for (size_t t0 = 0; t0 < tracks.size(); t0 += kSweepTracks) {
-                const size_t t1 = std::min(tracks.size(), t0 + (size_t)kSweepTracks);
-                if ((int64_t)(t1 - t0) < h->block_sweep_min_tracks) {
-                    for (size_t t = t0; t < t1; ++t) back.insert(back.end(), tracks[t].ks.begin(), tracks[t].ks.end());
-                    continue;
-                }
-                out.emplace_back();
-                for (size_t t = t0; t < t1; ++t) out.back().tr[t - t0] = std::move(tracks[t].ks);
-            }
-            i = j;
-        }
-    };
-
-#endif
-#ifdef MI_SPMM_ABLATE
-    std::vector<BlockItem> res_items;
-    std::vector<std::vector<Key>> pass_keys;
-#endif
     for (int pass = 0; pass < kMaxPieces; ++pass) {
         keys.clear();
         for (int32_t gi = 0; gi < ng; ++gi) {
             const GroupPieces &g = gp[(size_t)gi];
             for (int ord = 0; ord < g.n; ++ord) {
-                // (A/B library, "block_merge_unsafe": every ordinal lands in pass 0 -- one sweep, dependencies ignored)
-                if (h->block_merge_unsafe ? pass != 0 : ord != pass) continue;
+                if (ord != pass) continue;
                 Key k;
                 const int32_t c = g.c0[ord];
                 k.run = c >= 0 && g.len[ord] % run_unit == 0;      // any other run the run kernels cannot take: a list piece
@@ -298,88 +214,12 @@ static int build_block_items(mi_spmm_handle *h)
         }
         if (keys.empty()) break;
         n_pass = pass + 1;
-#ifdef MI_SPMM_ABLATE
-        if (sweeping) pass_keys.push_back(keys);
-#endif
         Launch al[3];
         form_items(keys, items, al, true);
         for (int c = 0; c < 3; ++c) { h->blk_launch[pass][c].off = al[c].off; h->blk_launch[pass][c].n = al[c].n; }
     }
     if (items.empty()) return MI_SPMM_OK;
 
-#ifdef MI_SPMM_ABLATE
-    // The second plan, used by full-row-range steps: sweeps + the items of everything the sweeps do not take (carried
-    // tiles have one layout, C's own: a group's pieces may ride the sweeps in one pass and be items in another).
-    std::vector<SweepWG> wgs;
-    std::vector<int32_t> trip_cols;
-    std::vector<SweepEnt> ents;
-    int32_t n_sweep_pieces = 0;
-    if (sweeping) {
-        std::vector<std::vector<WGPlan>> plans((size_t)n_pass);
-        std::vector<std::vector<Key>> rests((size_t)n_pass);
-        for (int pass = 0; pass < n_pass; ++pass) {
-            std::vector<Key> sw;
-            for (const Key &k : pass_keys[(size_t)pass]) {
-                const bool ok = k.run && k.col % kSweepTrip == 0 && k.len % kSweepTrip == 0 && gp[(size_t)k.gi].row_len < (1 << 24);
-                (ok ? sw : rests[(size_t)pass]).push_back(k);
-            }
-            form_sweeps(sw, rests[(size_t)pass], plans[(size_t)pass]);
-        }
-        std::vector<std::pair<int32_t, int32_t>> iv;
-        for (int pass = 0; pass < n_pass; ++pass) {
-            h->sweep_launch[pass].off = (int32_t)wgs.size();
-            for (WGPlan &w : plans[(size_t)pass]) {
-                iv.clear();
-                for (const auto &tr : w.tr)
-                    for (const Key &k : tr) iv.emplace_back(k.col, k.col + k.len);
-                if (iv.empty()) continue;
-                std::sort(iv.begin(), iv.end());
-                SweepWG rec;
-                rec.trip_begin = (int32_t)trip_cols.size();
-                // the trips: every 16 columns of the union of the tracks' pieces; per trip and track, what the track does
-                size_t cur[kSweepTracks] = {0};
-                int32_t sb = iv[0].first, se = iv[0].second;
-                auto emit_span = [&](int32_t b0, int32_t e0) {
-                    for (int32_t col = b0; col < e0; col += kSweepTrip) {
-                        trip_cols.push_back(col);
-                        for (int t = 0; t < kSweepTracks; ++t) {
-                            SweepEnt en = {-1, 0, 0, 0};
-                            const std::vector<Key> &tr = w.tr[t];
-                            while (cur[t] < tr.size() && tr[cur[t]].col + tr[cur[t]].len <= col) ++cur[t];
-                            if (cur[t] < tr.size() && tr[cur[t]].col <= col) {
-                                const Key &k = tr[cur[t]];
-                                const BlockPiece bp = piece_of(k);
-                                en.group = bp.group;
-                                en.flags = (col == k.col ? kSweepFirst : 0) | (col + kSweepTrip == k.col + k.len ? kSweepLast : 0) |
-                                           ((bp.flags & kPieceCarryIn) ? kSweepCarryIn : 0) | ((bp.flags & kPieceCarryOut) ? kSweepCarryOut : 0);
-                                en.a_off = bp.p0 + bp.k0 + (col - k.col);
-                                en.row_len = bp.row_len;
-                            }
-                            ents.push_back(en);
-                        }
-                    }
-                };
-                for (size_t q = 1; q < iv.size(); ++q) {
-                    if (iv[q].first <= se) se = std::max(se, iv[q].second);
-                    else {
-                        emit_span(sb, se);
-                        sb = iv[q].first;
-                        se = iv[q].second;
-                    }
-                }
-                emit_span(sb, se);
-                rec.n_trips = (int32_t)trip_cols.size() - rec.trip_begin;
-                wgs.push_back(rec);
-                n_sweep_pieces += (int32_t)iv.size();
-            }
-            h->sweep_launch[pass].n = (int32_t)wgs.size() - h->sweep_launch[pass].off;
-            Launch rl[3];
-            form_items(rests[(size_t)pass], res_items, rl, false);
-            for (int c = 0; c < 3; ++c) { h->blk_res_launch[pass][c].off = rl[c].off; h->blk_res_launch[pass][c].n = rl[c].n; }
-        }
-    }
-
-#endif
     auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
         if (bytes == 0) return MI_SPMM_OK;
         if (hipMalloc(dst, bytes) != hipSuccess) return MI_SPMM_ENOMEM;
@@ -389,21 +229,7 @@ static int build_block_items(mi_spmm_handle *h)
         return MI_SPMM_OK;
     };
     int rc = upload((void **)&h->d_blk_items, items.data(), items.size() * sizeof(BlockItem));
-#ifdef MI_SPMM_ABLATE
-    if (rc == MI_SPMM_OK && !wgs.empty()) {
-        rc = upload((void **)&h->d_sweep_wgs, wgs.data(), wgs.size() * sizeof(SweepWG));
-        if (rc == MI_SPMM_OK) rc = upload((void **)&h->d_sweep_cols, trip_cols.data(), trip_cols.size() * sizeof(int32_t));
-        if (rc == MI_SPMM_OK) rc = upload((void **)&h->d_sweep_ents, ents.data(), ents.size() * sizeof(SweepEnt));
-        if (rc == MI_SPMM_OK) rc = upload((void **)&h->d_blk_res_items, res_items.data(), res_items.size() * sizeof(BlockItem));
-    }
-#endif
     if (rc != MI_SPMM_OK) return rc;
-#ifdef MI_SPMM_ABLATE
-    h->n_sweep_pieces = n_sweep_pieces;
-    h->n_sweep_wgs = (int32_t)wgs.size();
-    h->n_sweep_trips = (int32_t)std::min<size_t>(trip_cols.size(), (size_t)INT32_MAX);
-    h->n_blk_res_items = (int32_t)res_items.size();
-#endif
     h->n_blk_items = (int32_t)items.size();
     h->n_blk_pieces = (int32_t)n_pieces;
     h->n_blk_passes = n_pass;
@@ -543,11 +369,6 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->block_share = 2;
     h->block_max_pieces = kMaxPieces;
     h->block_run_min = 32;
-#ifdef MI_SPMM_ABLATE
-    h->block_sweep = 0;
-    h->block_sweep_cols = 2048;
-    h->block_sweep_min_tracks = 4;
-#endif
     h->kernel = 2;
     h->gpu_preprocess = 1;
     h->block_threads = 256;
@@ -590,12 +411,8 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
     else if (k == "kernel") {
-#ifdef MI_SPMM_ABLATE
-        if (v != 1 && v != 2) return MI_SPMM_EINVAL;
-#else
-        if (v == 1) return MI_SPMM_EUNSUPPORTED;   // the first-generation rows kernel lives only in the A/B library (make ablate)
+        if (v == 1) return MI_SPMM_EUNSUPPORTED;   // the first-generation rows kernel was retired in round 3 (git history: 0894343)
         if (v != 2) return MI_SPMM_EINVAL;
-#endif
         h->kernel = v;
     }
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
@@ -610,12 +427,6 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "block_share") { if (v < 1 || v > kMaxShare) return MI_SPMM_EINVAL; h->block_share = v; free_plan(h); }
     else if (k == "block_max_pieces") { if (v < 1 || v > kMaxPieces) return MI_SPMM_EINVAL; h->block_max_pieces = v; free_plan(h); }
     else if (k == "block_run_min") { if (v < 1) return MI_SPMM_EINVAL; h->block_run_min = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
-#ifdef MI_SPMM_ABLATE
-    else if (k == "block_merge_unsafe") { h->block_merge_unsafe = v ? 1 : 0; free_plan(h); }
-    else if (k == "block_sweep") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->block_sweep = v; free_plan(h); }
-    else if (k == "block_sweep_cols") { if (v < kSweepTrip || v > (1 << 24) || v % kSweepTrip != 0) return MI_SPMM_EINVAL; h->block_sweep_cols = v; free_plan(h); }
-    else if (k == "block_sweep_min_tracks") { if (v < 1 || v > kSweepTracks) return MI_SPMM_EINVAL; h->block_sweep_min_tracks = v; free_plan(h); }
-#endif
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
 }
@@ -658,15 +469,6 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_block_pieces") *value = h->n_blk_pieces;
     else if (k == "n_block_passes") *value = h->n_blk_passes;
     else if (k == "n_block_shared_items") *value = h->n_blk_shared_items;
-#ifdef MI_SPMM_ABLATE
-    else if (k == "block_sweep") *value = h->block_sweep;
-    else if (k == "block_sweep_cols") *value = h->block_sweep_cols;
-    else if (k == "block_sweep_min_tracks") *value = h->block_sweep_min_tracks;
-    else if (k == "n_sweep_workgroups") *value = h->n_sweep_wgs;
-    else if (k == "n_sweep_pieces") *value = h->n_sweep_pieces;
-    else if (k == "n_sweep_trips") *value = h->n_sweep_trips;
-    else if (k == "n_block_residual_items") *value = h->n_blk_res_items;
-#endif
     else if (k == "preprocess_us") *value = (int64_t)h->preprocess_us;
     else if (k == "pre_d2h_us") *value = (int64_t)h->phase_us[0];
     else if (k == "pre_colcheck_us") *value = (int64_t)h->phase_us[1];
@@ -872,25 +674,6 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
 // ---- launch dispatch ------------------------------------------------------------
 namespace {
 
-#ifdef MI_SPMM_ABLATE
-// v1 rows kernel (per-row fetch, no prefetch): kept as the A/B baseline only, one configuration per shape.
-template <int V, bool WIDE>
-void launch_rows_v1(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
-{
-    switch (lpr) {
-    case 8: hipLaunchKernelGGL((spmm_rows<V, 8, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((spmm_rows<V, 16, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((spmm_rows<V, 32, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL((spmm_rows<V, 64, 8, WIDE, 1>), grid, dim3(kBlockThreads), 0, s, a); break;
-    }
-}
-void launch_rows_any(bool vec4, bool wide, int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
-{
-    if (vec4) { if (wide) launch_rows_v1<4, true>(lpr, a, grid, s); else launch_rows_v1<4, false>(lpr, a, grid, s); }
-    else { if (wide) launch_rows_v1<1, true>(lpr, a, grid, s); else launch_rows_v1<1, false>(lpr, a, grid, s); }
-}
-
-#endif  // MI_SPMM_ABLATE
 
 // v2 rows kernel: the cache policy (nt C stores x nt (col,val) loads) and the workgroup size are
 // instantiated for the 16-byte narrow path, which every benchmark shape uses; the dword and
@@ -1032,19 +815,18 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     if (vec4 && lpr > tile_cap) lpr = tile_cap;
     const int tile_w = lpr * V;
     const int col_tiles = (N + tile_w - 1) / tile_w;
-    const bool v2 = h->kernel == 2;
-    const int bt = (v2 && vec4 && !wide) ? (int)h->block_threads : kBlockThreads;
+    const int bt = (vec4 && !wide) ? (int)h->block_threads : kBlockThreads;
     const int gpb = bt / lpr;
     int rpb = (int)h->rows_per_block;
-    // v2: one row per lane group -- except narrow groups on very short rows (N <= 32, mean degree < 12), where a second
+    // one row per lane group -- except narrow groups on very short rows (N <= 32, mean degree < 12), where a second
     // row per group lets the next row's pairs be fetched under the current row's few gathers (+3-6 %, profiles/r01_thresholds.txt)
     const bool short_rows = lpr == 8 && M > 0 && h->nnz / M < 12;
-    if (rpb <= 0) rpb = v2 ? (short_rows ? 2 * gpb : gpb) : gpb * 8;
+    if (rpb <= 0) rpb = short_rows ? 2 * gpb : gpb;
     if (rpb < gpb) rpb = gpb;
-    int rpg = rpb / gpb;          // v2: contiguous rows per lane group, at most LPR - 1
+    int rpg = rpb / gpb;          // contiguous rows per lane group, at most LPR - 1
     if (rpg > lpr - 1) rpg = lpr - 1;
     if (rpg < 1) rpg = 1;
-    if (v2) rpb = rpg * gpb;
+    rpb = rpg * gpb;
     const int64_t nblk64 = ((int64_t)(row_end - row_begin) + rpb - 1) / rpb;
     if (nblk64 > INT32_MAX || col_tiles > 65535) return MI_SPMM_EUNSUPPORTED;
     // auto: measured neutral-to-positive everywhere except one whole-wave row and a single column
@@ -1097,41 +879,11 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ba.row_lo = row_begin;
         ba.row_hi = row_end;
         const int slab = block_slab_width(full.N), slabs = full.N / slab;
-#ifdef MI_SPMM_ABLATE
-        // full-row-range steps on 256-column slabs: the run pieces are swept on tracks, the items are what is left over
-        const bool sweep = h->n_sweep_wgs > 0 && slab == 256 && row_begin <= 0 && row_end >= h->num_v;
-        SweepArgs sa;
-        sa.wgs = nullptr;
-        sa.cols = h->d_sweep_cols;
-        sa.ents = h->d_sweep_ents;
-        sa.vals = h->d_val;
-        sa.B = full.B;
-        sa.C = full.C;
-        sa.ldb = ldb;
-        sa.ldc = ldc;
-        sa.n_wgs = 0;
-        sa.remap = remap_blocks ? 1 : 0;
-#endif
         // pass p continues the fma chains pass p-1 left in C: stream order is the dependency
         for (int pass = 0; pass < h->n_blk_passes; ++pass) {
-#ifdef MI_SPMM_ABLATE
-            if (sweep && h->sweep_launch[pass].n > 0) {
-                sa.wgs = h->d_sweep_wgs + h->sweep_launch[pass].off;
-                sa.n_wgs = h->sweep_launch[pass].n;
-                dim3 sgrid((unsigned)sa.n_wgs, slabs);
-                hipLaunchKernelGGL(spmm_block_sweep, sgrid, dim3(kBlockThreads), 0, s, sa);
-                ++launches;
-            }
-#endif
             for (int cls = 2; cls >= 0; --cls) {
                 int32_t n = h->blk_launch[pass][cls].n;
                 ba.items = h->d_blk_items + h->blk_launch[pass][cls].off;
-#ifdef MI_SPMM_ABLATE
-                if (sweep) {
-                    n = h->blk_res_launch[pass][cls].n;
-                    ba.items = h->d_blk_res_items + h->blk_res_launch[pass][cls].off;
-                }
-#endif
                 if (n == 0) continue;
                 ba.n_items = n;
                 dim3 bgrid((unsigned)((n + 3) / 4), slabs);
@@ -1153,7 +905,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     a.row0 = row_begin;
     a.M = row_end;
     a.N = N;
-    a.rows_per_block = v2 ? rpg : rpb;
+    a.rows_per_block = rpg;
     // rows above the medium threshold were given to the segment kernel -- except rows of block groups
     // when the block path cannot run here (pointers or pitches not 16-byte aligned): then the rows kernel takes every
     // unsplit row again (medium rows are computed twice with identical bits; stream order keeps it benign)
@@ -1165,10 +917,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     // every row may already be owned by the segment, split and block paths: nothing left to launch
     const bool rows_needed = !((blocks_on || h->n_blk_groups == 0) && h->n_rows_for_rows_kernel == 0);
     if (!rows_needed) { /* skip */ }
-    else if (v2) launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
-#ifdef MI_SPMM_ABLATE
-    else launch_rows_any(vec4, wide, lpr, a, grid, s);
-#endif
+    else launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
     if (rows_needed) ++launches;
 
     if (h->n_long > 0) {

@@ -56,26 +56,4 @@ struct BlockItem {                // what one wave sweeps: up to kMaxShare piece
 };
 static_assert(sizeof(BlockItem) == 64, "one item = one 64-byte record");
 
-// ---- block path, B-stationary sweeps (spmm_block_sweep) ----------------------------------------------
-// The host lays the run pieces on tracks and writes out, trip by trip, what every track of every workgroup does: the
-// kernel is an interpreter of that table (no piece bookkeeping on the device).
-constexpr int kSweepTracks = 6;   // tracks per workgroup = accumulator sets per wave (each wave: all tracks, one 64-column quarter of the slab)
-constexpr int kSweepAhead = 3;    // trips the B loads run ahead of the MFMAs (register sets)
-constexpr int kSweepTrip = 16;    // columns (B rows) per trip; sweepable pieces start and end on multiples of it
-
-constexpr int kSweepFirst = 1;    // the piece's first trip: accumulators start from +0 or from the carried tile
-constexpr int kSweepLast = 2;     // its last trip: the tile is stored (final rows, or the chain a later pass continues)
-constexpr int kSweepCarryIn = 4;
-constexpr int kSweepCarryOut = 8;
-
-struct SweepEnt {                 // one track during one trip (16 bytes; lane l of a wave loads track l's entry)
-    int32_t group;                // block group (rows 16*group ..) of the piece under this trip's columns; -1: none
-    int32_t flags;                // kSweep*
-    int32_t a_off;                // vals index of (first row of the group, this trip's first column)
-    int32_t row_len;              // nonzeros per row of the group (row i of the group: a_off + i * row_len)
-};
-static_assert(sizeof(SweepEnt) == 16, "sweep entry");
-
-struct SweepWG { int32_t trip_begin, n_trips; };   // a workgroup's trips in the trip tables (cols[], ents[][kSweepTracks])
-
 }  // namespace mi

@@ -160,11 +160,15 @@ __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__
     }
 }
 
+// Temporaries are carved out of two grow-only arenas the handle owns (plan.hpp Scratch).  What is guaranteed: between the
+// first launch of a preprocess and the copy-back of its statistics there is no allocation call at all, and no temporary
+// ever comes from hipMallocAsync's pool; a repeated preprocess allocates no temporaries.  What still allocates: the
+// plan's OUTPUT tables (segments, hub rows, block groups) are synchronous hipMalloc calls placed after that copy-back has
+// been waited for (at most the block-group list's device-to-device copy is in flight then; no kernel is).  (Round 2: pool buffers allocated while earlier kernels of the same
+// preprocess were in flight were seen overlapping rocPRIM's scan state in a torch-free process -- the plan statistics
+// came back zeroed now and then.  Two changes went in together -- pool -> arenas, hipMemsetAsync(stats) -> init kernel --
+// and which of them removed the failure was not isolated; test_native_harness_end_to_end is the regression.)
 namespace {
-// Temporaries are carved out of two grow-only arenas the handle owns (plan.hpp Scratch): no allocation call sits
-// between the kernel launches of a preprocess, and a repeated preprocess allocates nothing.  (Round 2: buffers from
-// hipMallocAsync's pool, allocated while earlier kernels of the same preprocess were in flight, were seen overlapping
-// rocPRIM's scan state in a torch-free process -- the plan statistics came back zeroed now and then.)
 struct Carver {
     char *base;
     size_t off = 0;

@@ -12,8 +12,6 @@
 //
 //   spmm_rows_v2     short rows; a lane group per row, lanes own output columns, no cross-lane
 //                    reduction -> bit-identical to the reference kernel   
-//   spmm_rows        the first version of the same (per-row fetch, no prefetch): A/B baseline, only in the
-//                    -DMI_SPMM_ABLATE library (make -C hpc_amd/csrc ablate); not in the product
 //   spmm_chunks      medium rows as ONE exact segment each (straight to C) and hub rows as pieces
 //   spmm_reduce_chunks   ... whose partial sums are added left to right (deterministic; the only
 //                    place where the summation order differs from the reference)   (4.2)
@@ -130,108 +128,6 @@ __device__ __forceinline__ const float *b_row_ptr(const float *B, int64_t ldb, u
     return reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
 }
 
-#ifdef MI_SPMM_ABLATE   // first-generation rows kernel: built only into the A/B library (make ablate), never shipped
-// The fma chain of one segment [beg, end) of nonzeros for this lane's V
-// output columns.  Group-uniform control flow: all LPR lanes of a group see
-// the same beg/end.  The group fetches LPR (col, val) pairs with one
-// coalesced dword load each, then walks them in order in batches of UNROLL:
-// UNROLL independent B-row loads (V*4 bytes per lane, LPR*V*4 contiguous bytes
-// per row) are issued before the dependent fma chain consumes them, so each
-// wave keeps UNROLL requests of up to 1 KiB in flight.  Full batches carry no
-// predicates; the last partial batch of a fetch is predicated per load.
-template <int V, int LPR, int UNROLL, bool WIDE, bool NT_STREAM>
-__device__ __forceinline__ typename Vec<V>::T
-segment_chain(const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
-              const float *__restrict__ B, int64_t ldb, int col, int beg, int end,
-              int lig)
-{
-    typedef typename Vec<V>::T T;
-    T acc = Vec<V>::zero();
-    const uint32_t ldb_bytes = (uint32_t)ldb * 4u, col_bytes = (uint32_t)col * 4u;
-    for (int k0 = beg; k0 < end; k0 += LPR) {
-        const int k = k0 + lig;
-        int ci = 0;
-        float av = 0.f;
-        if (k < end) {
-            if (NT_STREAM) {
-                ci = __builtin_nontemporal_load(col_idx + k);
-                av = __builtin_nontemporal_load(vals + k);
-            } else {
-                ci = col_idx[k];
-                av = vals[k];
-            }
-        }
-        const int avi = __float_as_int(av);
-        const int cnt = min(LPR, end - k0);
-        int j = 0;
-        for (; j + UNROLL <= cnt; j += UNROLL) {
-            T b[UNROLL];
-            float a[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int c = group_bcast<LPR>(ci, j + u);
-                a[u] = __int_as_float(group_bcast<LPR>(avi, j + u));
-                b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) acc = Vec<V>::fma(b[u], a[u], acc);
-        }
-        if (UNROLL > 1 && j < cnt) {
-            T b[UNROLL];
-            float a[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL - 1; ++u) {
-                const int jj = j + u;  // < LPR because UNROLL divides LPR
-                const int c = group_bcast<LPR>(ci, jj);
-                a[u] = __int_as_float(group_bcast<LPR>(avi, jj));
-                b[u] = Vec<V>::zero();
-                if (jj < cnt) b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
-            }
-            // slots past the segment carry a = +0 (lane k >= end loaded nothing) and
-            // b = +0: fma(0, 0, acc) == acc bit for bit (acc is never -0: it starts
-            // at +0 and a sum is -0 only when both addends are)
-#pragma unroll
-            for (int u = 0; u < UNROLL - 1; ++u) acc = Vec<V>::fma(b[u], a[u], acc);
-        }
-    }
-    return acc;
-}
-
-// ---- rows kernel: exact-order path -------------------------------------------
-// grid.x = ceil(M / rows_per_block), grid.y = ceil(N / (LPR*V)) column tiles,
-// block = 256 threads = 256/LPR lane groups; a group owns one row at a time.
-template <int V, int LPR, int UNROLL, bool WIDE, int POL>
-__global__ __launch_bounds__(kBlockThreads) void spmm_rows(RowsArgs a)
-{
-    constexpr int GPB = kBlockThreads / LPR;  // groups per block
-    const int tid = threadIdx.x;
-    const int g = tid / LPR;
-    const int lig = tid % LPR;
-    const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(blockIdx.x, a.nblk) : (int)blockIdx.x;
-    const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
-    const bool col_ok = col_raw < a.N;
-    // lanes past N load a valid column and store nothing; when N is not a multiple of V the row's last lane is
-    // shifted back to N - V: it recomputes up to V-1 columns of its neighbour and both store the same bits
-    const int col = min(col_raw, a.N - V);
-
-    const int r0 = a.row0 + vb * a.rows_per_block;
-    const int r1 = min(a.M, r0 + a.rows_per_block);
-    for (int r = r0 + g; r < r1; r += GPB) {
-        int beg = a.row_ptr[r];
-        int end = a.row_ptr[r + 1];
-        if (LPR == 64) {  // whole wave on one row: make the bounds scalar
-            beg = __builtin_amdgcn_readfirstlane(beg);
-            end = __builtin_amdgcn_readfirstlane(end);
-        }
-        if (end - beg > a.long_thr) continue;  // chunk path owns this row
-        if (a.blk_flag && a.blk_flag[r >> 4]) continue;  // block path owns this 16-row group
-        typename Vec<V>::T acc = segment_chain<V, LPR, UNROLL, WIDE, (POL & kPolNtStream) != 0>(
-            a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
-        if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)r * a.ldc + col, acc);
-    }
-}
-
-#endif  // MI_SPMM_ABLATE
 
 // ---- rows kernel v2: same arithmetic, software-pipelined over (row, chunk) items ----
 // v1 above serialises three memory round trips per row (row_ptr -> (col,val) -> B rows) and
@@ -870,161 +766,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
     }
 }
 
-#ifdef MI_SPMM_ABLATE
-// ---- block path, B-stationary sweeps: EXPERIMENT, A/B library only (make -C hpc_amd/csrc ablate) ---------------
-// The item kernel gives every wave its own stretch of B: a 128-column run reaches its second half one half-item after
-// the items STARTING there have read it, and the XCD's 4 MB L2 has turned over several times by then -- B crosses the
-// fabric ~1.7 times per pass.  Here the column axis is cut into long segments and the run pieces that start in a
-// segment are laid on 8 TRACKS (interval partitioning on the host: a track's pieces are disjoint and ascending).
-// A wave sweeps the segment once, in trips of 16 columns = 16 B rows, for ALL 8 tracks but only for a 64-column
-// quarter of the 256-column slab (the 4 waves of a workgroup take the 4 quarters): 8 accumulator sets of 4 tiles.
-//   * every B register feeds up to 8 MFMAs, and every consumer of a B row in the segment is the SAME wave: B crosses
-//     the fabric once per pass by construction, with no LDS, no barrier and no timing assumption;
-//   * the A operands of the 8 tracks (16 x 16 values per trip and track) are read by each of the 4 quarter-waves
-//     (the same lines a few hundred cycles apart: L2 hits);
-//   * what each track does in each trip -- nothing, multiply, start a piece (from +0 or from the tile an earlier pass
-//     carried), end one (store the tile) -- is a table the host wrote (SweepEnt): the kernel keeps no piece state.
-// The arithmetic per output element is untouched (same k order, same MFMA chain as spmm_block_items).
-//
-// Carried tiles have the layout of C itself (as in spmm_block_items): a group's pieces may ride the sweeps in one pass and
-// be items in another.
-// (First design, profiles/r02_c4_block_path_notes.txt: 2 tracks per wave over the full slab, B through an LDS-DMA ring
-// with a workgroup barrier per trip -- right traffic, 1.35-2.1 ms: too little matrix work per barrier.)
-struct SweepArgs {
-    const SweepWG *wgs;
-    const int32_t *cols;       // [trip]: first B row of the trip
-    const SweepEnt *ents;      // [trip][kSweepTracks]
-    const float *vals;
-    const float *B;
-    float *C;
-    int64_t ldb;
-    int64_t ldc;
-    int32_t n_wgs;
-    int32_t remap;
-};
-
-typedef int int4i __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) int32_t *SweepColPtr;     // wave-uniform reads through the scalar cache
-
-__global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_sweep(SweepArgs a)
-{
-    constexpr int TR = kSweepTracks, QT = 4;   // tracks per wave; 16-column tiles per quarter
-    typedef float4v BV;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int vblk = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    if (vblk >= a.n_wgs) return;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int colv = (int)blockIdx.y * 256 + 64 * wave + 4 * i16;     // this lane's 4 columns: tile e = column colv + e ... of 16-lane rows
-    const SweepColPtr wrec = (SweepColPtr)reinterpret_cast<const int32_t *>(a.wgs + vblk);
-    const int trip_begin = wrec[0], T = wrec[1];
-    const SweepColPtr cols = (SweepColPtr)(a.cols + trip_begin);
-    const int4i *ents = reinterpret_cast<const int4i *>(a.ents) + (int64_t)trip_begin * TR + ((lane & 7) < TR ? (lane & 7) : TR - 1);   // lane l < TR keeps track l's entry
-
-    // A trip's operands: B rows 4s + kq (this lane's 4 columns) and, per track, A values 4kq..4kq+3 of row i16.
-    // Every B row is read by this wave and nobody else, i.e. always from HBM: its loads run kSweepAhead trips ahead
-    // (a trip of a sparsely occupied wave is short); the A lines are shared with the other three quarter-waves.
-    constexpr int AH = kSweepAhead;
-    struct BOps { BV b[4]; };
-    struct AOps { float4v araw[TR]; };
-    auto table = [&](int u) { return ents[(int64_t)(u < T ? u : T - 1) * TR]; };
-    auto column = [&](int u) { return cols[u < T ? u : T - 1]; };
-    auto fetch_b = [&](BOps &P, int col) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) P.b[s4] = *reinterpret_cast<const BV *>(a.B + (int64_t)(col + 4 * s4 + kq) * a.ldb + colv);
-    };
-    auto fetch_a = [&](AOps &P, const int4i &E) {
-#pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            const int a_off = __builtin_amdgcn_readlane(E[2], j), rl = __builtin_amdgcn_readlane(E[3], j);   // idle track: 0, 0 (any valid address)
-            P.araw[j] = Vec<4>::load(a.vals + a_off + i16 * rl + 4 * kq);
-        }
-    };
-
-    float4a acc[TR][QT];
-#pragma unroll
-    for (int j = 0; j < TR; ++j)
-#pragma unroll
-        for (int e = 0; e < QT; ++e) acc[j][e] = (float4a){0.f, 0.f, 0.f, 0.f};
-
-    // one trip: pieces that start (before the loads go out: a wait for a carried tile must not drain them), the loads
-    // for later trips, then per busy track the 16 MFMAs of the trip and, where its piece ends, the tile store
-    BOps Bq[AH + 1];                      // Bq[k]: trip t + k
-    auto trip = [&](const AOps &P, AOps &Pn, const int4i &E, const int4i &En, int col_far) {
-#pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            const int grp = __builtin_amdgcn_readlane(E[0], j), fl = __builtin_amdgcn_readlane(E[1], j);
-            if (grp >= 0 && (fl & kSweepFirst)) {
-                if (fl & kSweepCarryIn) {                // the chain an earlier pass (sweep or item) left in C: row r0 + 4kq + q holds register q of tiles 0..3
-                    const float *cp = a.C + (int64_t)((grp << 4) + 4 * kq) * a.ldc + colv;
-                    BV t4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) t4[q] = *reinterpret_cast<const BV *>(cp + (int64_t)q * a.ldc);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < QT; ++e) acc[j][e][q] = t4[q][e];
-                } else {
-#pragma unroll
-                    for (int tl = 0; tl < QT; ++tl) acc[j][tl] = (float4a){0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_b(Bq[AH], col_far);
-        fetch_a(Pn, En);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            const int grp = __builtin_amdgcn_readlane(E[0], j), fl = __builtin_amdgcn_readlane(E[1], j);
-            if (grp >= 0) {
-                // 4x4 transpose across the kq rows of the wave: lane (i16, kq) gets a[row i16][k = 4s + kq], s = 0..3
-                const unsigned v0 = __float_as_uint(P.araw[j][0]), v1 = __float_as_uint(P.araw[j][1]);
-                const unsigned v2 = __float_as_uint(P.araw[j][2]), v3 = __float_as_uint(P.araw[j][3]);
-                const auto r02 = __builtin_amdgcn_permlane32_swap(v0, v2, false, false);
-                const auto r13 = __builtin_amdgcn_permlane32_swap(v1, v3, false, false);
-                const auto s01 = __builtin_amdgcn_permlane16_swap(r02[0], r13[0], false, false);
-                const auto s23 = __builtin_amdgcn_permlane16_swap(r02[1], r13[1], false, false);
-                const float af[4] = {__uint_as_float(s01[0]), __uint_as_float(s01[1]), __uint_as_float(s23[0]), __uint_as_float(s23[1])};
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int e = 0; e < QT; ++e)
-                        acc[j][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4], Bq[0].b[s4][e], acc[j][e], 0, 0, 0);
-                if (fl & kSweepLast) {
-                    const int r0 = grp << 4;
-                    // register q of the tiles 0..3 is the float4 C[r0 + 4kq + q][colv ..]; a tile a later pass continues stays cacheable
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        BV v;
-#pragma unroll
-                        for (int e = 0; e < QT; ++e) v[e] = acc[j][e][q];
-                        BV *dst = reinterpret_cast<BV *>(a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + colv);
-                        if (fl & kSweepCarryOut) *dst = v;
-                        else __builtin_nontemporal_store(v, dst);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < AH; ++k) Bq[k] = Bq[k + 1];
-    };
-
-    AOps P0, P1;
-    int4i E0 = table(0), E1 = table(1);
-#pragma unroll
-    for (int k = 0; k < AH; ++k) fetch_b(Bq[k], column(k));
-    fetch_a(P0, E0);
-    for (int t = 0; t < T; t += 2) {
-        const int4i E2 = table(t + 2);
-        const int c1 = column(t + AH), c2 = column(t + AH + 1);
-        trip(P0, P1, E0, E1, c1);
-        if (t + 1 < T) trip(P1, P0, E1, E2, c2);
-        E0 = E2;
-        E1 = table(t + 3);
-    }
-}
-#endif  // MI_SPMM_ABLATE (sweeps)
 
 // Cuts a qualifying group's column list (the list of its first row) into runs of consecutive columns.
 // One wave per group.  out[gi]: n = number of pieces (1..kMaxPieces); piece r covers positions

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes for one command (GPU box): kernel trace + stats, then the PMC passes of MI355X_MICROARCH.md
 # (separate --pmc runs, never combined with a trace).  Output: gpurun_out/<tag>_{stats,fetch,write,tcc,sq}/ (csv).
-#   scripts/prof.sh r02_c4 python3 scripts/c4_ab.py --one 2 4 --steps 20
+#   scripts/prof.sh r03_c4 python3 bench.py --config C4 --steps 20 --warmup 5 --no-cpu-baseline
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out

@@ -387,8 +387,9 @@ def test_block_groups_with_long_lane_group_runs(device, oracle, N, rpb):
 
 
 def test_product_library_refuses_ablation_options(device):
-    """The first-generation rows kernel and the timing-only block-kernel builds exist only in the A/B library
-    (make -C hpc_amd/csrc ablate); the shipped ABI has no option that can produce a wrong C."""
+    """The first-generation rows kernel, the timing-only block-kernel builds and the B-stationary sweep experiment were
+    removed from the tree in round 3 (record: profiles/r02_c4_block_path_notes.txt, git 0894343); the ABI has no option
+    that can produce a wrong C."""
     import torch
     from hpc_amd import CSR, SpMMOpt
     from hpc_amd.spmm import MiSpmmError
@@ -476,58 +477,6 @@ def test_block_path_shared_runs_and_passes(device, oracle, N):
             assert op2.get_option("n_block_shared_items") == 0
         if opts.get("block_max_pieces") == 1:
             assert op2.get_option("n_block_passes") == 1 and op2.get_option("n_block_pieces") == op2.get_option("n_block_groups")
-
-
-@pytest.mark.parametrize("N,seg_cols,min_tracks,slots,min_gap", [(256, 1024, 1, 12, 0), (256, 256, 3, 12, 0), (512, 64, 1, 24, 0), (256, 4096, 5, 6, 0), (768, 512, 2, 24, 0),
-                                                                 (256, 1024, 4, 90, 4), (256, 512, 1, 90, 4), (512, 2048, 6, 46, 2)])
-def test_block_sweeps_bitwise(device, oracle, N, seg_cols, min_tracks, slots, min_gap):
-    """EXPERIMENT, A/B library only (make -C hpc_amd/csrc ablate; MI_SPMM_LIB=hpc_amd/libmi_spmm_ablate.so pytest -k block_sweeps):
-    B-stationary sweeps ("block_sweep" = 1).  Run pieces whose first column and length are multiples of 16 ride on tracks
-    (they start from zero or carried accumulators and leave with a tile store, workgroups skip the gaps between their
-    spans), everything else -- odd lengths, lists, tracks too few for a workgroup -- stays
-    items.  Same bits as the oracle and as the item-only plan; a row-range step falls back to the items.  The shipped
-    library has no such option (test_product_library_refuses_ablation_options): skipped there."""
-    import torch
-    from hpc_amd import CSR, SpMMOpt
-    from hpc_amd._lib import LIB_PATH
-
-    if "ablate" not in os.path.basename(LIB_PATH):
-        pytest.skip("block sweeps exist only in the A/B library (profiles/r02_c4_block_path_notes.txt: measured slower than the items)")
-
-    ptr, idx, vals, B = _run_groups_case(420, 6000, N, seed=8800 + N + seg_cols, lens=(32, 48, 64, 96, 128, 33, 208, 16), slots=slots, align=16, min_gap=min_gap)
-    g = np.random.Generator(np.random.Philox(key=[5, seg_cols]))
-    special = np.array([np.inf, -np.inf, np.nan, -0.0, 1e-40, 3.4e38], np.float32)
-    B = B.copy()
-    B.reshape(-1)[g.integers(0, B.size, 200)] = special[g.integers(0, special.size, 200)]
-    ref = oracle.spmm_omp(ptr, idx, vals, B)
-    opts = {"long_row_threshold": 2048, "block_sweep": 1, "block_sweep_cols": seg_cols, "block_sweep_min_tracks": min_tracks}
-    C, op = run_spmm(device, ptr, idx, vals, B, options=opts)
-    assert op.get_option("n_sweep_workgroups") > 0 and op.get_option("n_sweep_pieces") > (30 if min_tracks >= 6 else 100)
-    assert op.get_option("n_block_residual_items") > 0
-    assert op.get_option("n_sweep_pieces") < op.get_option("n_block_pieces")
-    assert np.array_equal(bits(C), bits(ref)), f"{(bits(C) != bits(ref)).any(axis=1).sum()} rows differ"
-    C0, op0 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 2048})
-    assert op0.get_option("n_sweep_workgroups") == 0
-    assert np.array_equal(bits(C0), bits(ref))
-    # repeated steps over a dirty C, and row panels (items) into the same buffer
-    M = ptr.size - 1
-    d = [torch.from_numpy(a).to(device) for a in (ptr, idx, vals)]
-    dB = torch.from_numpy(B).to(device)
-    dC = torch.full((M, N), float("nan"), device=device)
-    sp = SpMMOpt(CSR(M, idx.size, *d), N, num_cols=6000)
-    for k, v in opts.items():
-        sp.set_option(k, v)
-    sp.preprocess(dB, dC)
-    for _ in range(3):
-        sp.run(dB, dC)
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(dC.cpu().numpy()), bits(ref))
-    dC.fill_(float("nan"))
-    cut = (M // 3) // 16 * 16
-    sp.run_rows(dB, N, dC, N, 0, cut)
-    sp.run_rows(dB, N, dC, N, cut, M)
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(dC.cpu().numpy()), bits(ref))
 
 
 def test_block_items_row_panels_pitches_and_special_values(device, oracle):
