@@ -431,9 +431,13 @@ def main():
             except Exception:
                 traffic = None
         n_long = op.get_option("n_long_rows")
-        split_mode = ("exact: every row one fma chain in stored order" if n_long == 0 else
-                      f"auto: {n_long} rows above {op.get_option('long_row_threshold')} nonzeros summed in pieces of "
-                      f"{op.get_option('long_row_chunk')} (bit-exact vs the same piece order; <= 1e-5*sum|a*b| vs the plain chain)")
+        if op.get_option("split_long_rows") and n_long > 0:
+            split_mode = (f"opt-in split: {n_long} rows above {op.get_option('long_row_threshold')} nonzeros summed in pieces of "
+                          f"{op.get_option('long_row_chunk')} (bit-exact vs the same piece order; <= 1e-5*sum|a*b| vs the plain chain)")
+        else:
+            split_mode = ("exact: every row one fma chain in stored order" +
+                          (f" ({op.get_option('n_hub_rows')} rows above {op.get_option('long_row_threshold')} nonzeros through the hub kernel)"
+                           if op.get_option("n_hub_rows") else ""))
         n_blk = op.get_option("n_block_groups")
         if n_blk * 16 * 2 > M and not multi:
             # block-dense input: the step is the MFMA block kernels (BASELINE configs[4])
@@ -470,7 +474,7 @@ def main():
                 "parallelism": "single GPU" if world == 1 else f"column-sharded x{world}, C blocks exchanged over RCCL/xGMI ({exchange} schedule, "
                                f"{step_path}), {args.panels} row panels",
                 "options": {k: op.get_option(k) for k in ("kernel", "rows_per_block", "block_threads", "xcd_remap", "nt_store", "nt_stream",
-                                                          "medium_row_threshold", "long_row_threshold", "long_row_chunk", "segment_unroll", "n_long_rows", "n_chunks",
+                                                          "medium_row_threshold", "long_row_threshold", "split_long_rows", "n_hub_rows", "hub_overlap", "segment_unroll", "n_long_rows", "n_chunks",
                                                           "lanes_per_row", "vector_width", "n_launches", "tile_cols")},
                 "preprocess_ms": round(t_pre * 1e3, 2), "preprocess_first_call_ms": round(t_pre_first * 1e3, 2), "input_gen_s": round(t_gen, 1),
             },

@@ -36,6 +36,15 @@ struct mi_spmm_handle {
     int64_t long_thr_user;  // what the caller asked for (0 = auto); long_thr holds the resolved value
     int64_t medium_thr;  // rows longer than this (and not split) run as one exact segment in the segment kernel; 0 = auto
     int64_t medium_res;  // the value in force after preprocess (auto resolved, capped by long_thr)
+    int64_t split_long;   // 0 (default): hubs keep their stored order (spmm_hub); 1: hubs are cut into pieces summed piece by piece
+    int64_t hub_slice;    // columns per hub wave: 16, 32, 64; 0 = auto
+    int64_t hub_kernel;   // 2 (default): loader waves + chain wave (spmm_hub2); 1: one wave per slice fed by LDS-DMA (spmm_hub)
+    int64_t hub_overlap;  // 1 (default): the hub kernel and the segment kernel run on handle-owned side streams, forked from and joined
+                          // back into the caller's stream inside every run call (their longest rows then overlap the rows kernel)
+    hipStream_t side[2];  // [0]: hub kernel, [1]: segment (+ reduce) kernels; created by the first preprocess that needs them
+    hipEvent_t ev_fork, ev_join[2];
+    bool fork_recorded, forked[2];   // state of the current run_rows call
+    bool overlap_on[2];   // resolved by preprocess: is the fork/join (~20 us of launch latency per call) worth it for this class
     int64_t long_thr, long_chunk, rows_per_block, xcd_remap, nt_store, nt_stream, block_path;
     int64_t block_threads;  // v2 workgroup size: 64, 128 or 256
     int64_t gpu_preprocess;  // 1: segment table built on the device (default); 0: reference-style host loop
@@ -237,6 +246,47 @@ static int build_block_items(mi_spmm_handle *h)
     return MI_SPMM_OK;
 }
 
+// The hub kernel's longest row is the step's longest dependent chain; on a side stream it runs beside the rows kernel
+// instead of in front of it.  The stream and its two events belong to the handle (created once, here, never in run()).
+static int ensure_side_streams(mi_spmm_handle *h)
+{
+    // A fork + join costs ~20 us of launch latency per run call (ddi-shaped N = 32: 0.047 -> 0.069 ms): worth it once the
+    // step is long enough to hide something behind (estimate >= 0.2 ms) or the longest hub alone is a 50 us chain.
+    // "hub_overlap": 0 = never, 1 = this rule, 2 = always.
+    const double bytes = (double)h->nnz * (4.0 * h->feat + 8.0) + 4.0 * (double)h->num_v * h->feat;
+    const bool long_step = bytes / 6e12 >= 200e-6;
+    const bool exact_hubs = h->n_long > 0 && !h->split_long;
+    h->overlap_on[0] = exact_hubs && (h->hub_overlap == 2 || (h->hub_overlap == 1 && (long_step || h->max_row_nnz >= 7000)));
+    h->overlap_on[1] = h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
+    if (!(h->overlap_on[0] || h->overlap_on[1]) || h->side[0]) return MI_SPMM_OK;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    return MI_SPMM_OK;
+}
+
+// The stream kernel class i of this run_rows call goes to: side stream i, made to wait for what the caller's stream holds
+// so far (one fork event per call), or the caller's stream itself when overlap is off.
+static int side_stream(mi_spmm_handle *h, int i, hipStream_t s, hipStream_t *out)
+{
+    *out = s;
+    if (!h->overlap_on[i] || !h->side[i]) return MI_SPMM_OK;
+    if (!h->fork_recorded) {
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        h->fork_recorded = true;
+    }
+    if (!h->forked[i]) {
+        HIP_TRY(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
+        h->forked[i] = true;
+    }
+    *out = h->side[i];
+    return MI_SPMM_OK;
+}
+
 // preprocess with no host pass over the rows: column check, block detection, classification, scans,
 // segment emission and the length sort all run on the device; one small copy comes back.
 static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_point t0)
@@ -266,16 +316,17 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     if (h->block_path && block_path_shape_ok(h->feat) && M >= 16 && h->nnz > 0) {
         const int32_t n_groups = (M + 15) / 16;
         if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
+        // a group's shared list may be as long as the longest exact segment (auto hub threshold: at most its largest candidate)
         hipLaunchKernelGGL(detect_row_blocks, dim3((n_groups + 3) / 4), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M, (int32_t)h->nnz,
-                           (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
+                           (int32_t)h->block_min_len, (int32_t)(h->long_thr > 0 ? h->long_thr : hist_threshold(kHistN - 1)), h->d_blk_flag);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { free_plan(h); return (int)e; }
     }
     lap(2);
     PlanOut po;
-    const int32_t mthr = (int32_t)(h->medium_thr < h->long_thr ? h->medium_thr : h->long_thr);   // 0 = auto
-    const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
-                                  (int32_t)h->long_chunk, &h->scratch_a, &h->scratch_b, &po);
+    const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
+    const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
+                                  (int32_t)h->long_chunk, (int32_t)h->split_long, &h->scratch_a, &h->scratch_b, &po);
     h->d_chunks = po.d_chunks;
     h->d_long = po.d_long;
     h->d_blk_groups = po.d_blk_groups;
@@ -287,6 +338,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     h->n_blk_groups = po.n_blk_groups;
     h->max_row_nnz = po.max_len;
     h->medium_res = po.mthr;
+    h->long_thr = po.thr;
     h->local_pct = po.local_pct;
     if (h->n_blk_groups == 0 && h->d_blk_flag) { (void)hipFree(h->d_blk_flag); h->d_blk_flag = nullptr; }
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)h->n_medium;
@@ -303,6 +355,10 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         if (brc != 0) { free_plan(h); return brc; }
     }
     lap(4);
+    {
+        const int src = ensure_side_streams(h);
+        if (src != 0) { free_plan(h); return src; }
+    }
     h->prepared = true;
     h->preprocess_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return MI_SPMM_OK;
@@ -359,6 +415,10 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->medium_thr = 0;     // auto: 64, or 32 on skewed degree distributions (resolved in preprocess)
     h->long_thr = 0;       // 0 = auto, resolved in preprocess: clamp(nnz / 8192, 256, 2048)
     h->long_thr_user = 0;
+    h->split_long = 0;     // every row one chain in stored order (the reference's definition, spmm_ref.cu:10-14)
+    h->hub_slice = 0;
+    h->hub_overlap = 1;
+    h->hub_kernel = 2;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
     h->xcd_remap = -1;     // auto (see run)
@@ -396,6 +456,11 @@ int mi_spmm_destroy(mi_spmm_handle *h)
     scratch_release(&h->scratch_a);
     scratch_release(&h->scratch_b);
     if (h->d_col_bad) (void)hipFree(h->d_col_bad);
+    for (int i = 0; i < 2; ++i) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     h->magic = 0;
     delete h;
     return MI_SPMM_OK;
@@ -407,6 +472,10 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     const std::string k(key);
     if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
+    else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
+    else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
+    else if (k == "hub_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->hub_overlap = v; free_plan(h); }
+    else if (k == "hub_kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->hub_kernel = v; }
     else if (k == "long_row_chunk") { if (v < 1 || v > kMaxLongChunk) return MI_SPMM_EINVAL; h->long_chunk = v; free_plan(h); }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
@@ -440,6 +509,11 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_medium_rows") *value = h->n_medium;
     else if (k == "n_partial_slots") *value = h->n_slots;
     else if (k == "long_row_chunk") *value = h->long_chunk;
+    else if (k == "split_long_rows") *value = h->split_long;
+    else if (k == "hub_slice") *value = h->hub_slice;
+    else if (k == "hub_overlap") *value = h->hub_overlap;
+    else if (k == "hub_kernel") *value = h->hub_kernel;
+    else if (k == "n_hub_rows") *value = h->split_long ? 0 : h->n_long;
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
     else if (k == "kernel") *value = h->kernel;
@@ -492,15 +566,19 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MI_SPMM_ENODEVICE;
 
     const int32_t M = h->num_v;
-    // Split threshold.  Rows up to it stay ONE exact segment; longer ones (hubs) are cut into pieces so
-    // that no single lane group holds a noticeable share of the work.  auto: 2048 once there is enough
-    // work to hide a 2048-nonzero segment (nnz >= 2^24), proportionally lower for small matrices
-    // (profiles/r01_thresholds.txt).  An explicit value is taken as is.
+    // Hub threshold.  Rows up to it stay ONE exact segment of the segment kernel; longer ones (hubs) go to the hub kernel
+    // (stored order) or, with "split_long_rows", are cut into pieces.  An explicit value is taken as is.  auto:
+    //   split mode: 2048 once there is enough work to hide a 2048-nonzero segment (nnz >= 2^24), proportionally lower for
+    //     small matrices (profiles/r01_thresholds.txt);
+    //   default (exact) mode: plan.hpp resolve_hub_threshold (needs the row-length histogram: resolved inside the plan builders).
     if (h->long_thr_user > 0) h->long_thr = h->long_thr_user;
-    else {
+    else if (h->split_long) {
         int64_t t = h->nnz / 8192;
         h->long_thr = t < 256 ? 256 : (t > 2048 ? 2048 : t);
-    }
+    } else h->long_thr = 0;     // resolved by the plan builder from the row-length histogram (plan.hpp: resolve_hub_threshold)
+    // The hub kernel moves 16-byte parts of B rows: a B narrower than one part keeps its long rows as single exact
+    // segments of the segment kernel (slow on a real hub, but N < 4 has no bandwidth to speak of either way).
+    if (!h->split_long && h->feat < 4) h->long_thr = INT32_MAX;
     if (h->gpu_preprocess) return preprocess_on_gpu(h, t0);
     std::vector<int32_t> ptr((size_t)M + 1);
     HIP_TRY(hipMemcpy(ptr.data(), h->d_ptr, sizeof(int32_t) * ((size_t)M + 1), hipMemcpyDeviceToHost));
@@ -515,6 +593,17 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     }
     if (ptr[0] != 0 && (int64_t)ptr[0] > h->nnz) return MI_SPMM_ECSR;
     h->max_row_nnz = max_len;
+    // (as in the device builder: a block group's list may be as long as the largest candidate of the auto threshold)
+    const int32_t detect_max = (int32_t)(h->long_thr > 0 ? h->long_thr : hist_threshold(kHistN - 1));
+    if (h->long_thr == 0) {      // auto, exact mode: the same histogram and the same rule as the device builder
+        LenHist hist;
+        std::memset(&hist, 0, sizeof(hist));
+        for (int32_t r = 0; r < M; ++r) {
+            const int32_t len = ptr[r + 1] - ptr[r];
+            for (int i = 0; i < kHistN && len > hist_threshold(i); ++i) { ++hist.cnt[i]; hist.nnz[i] += (unsigned long long)len; }
+        }
+        h->long_thr = resolve_hub_threshold(h->nnz, M, h->feat, hist.nnz);
+    }
     auto lap = [&](int i, std::chrono::steady_clock::time_point &from) {
         const auto now = std::chrono::steady_clock::now();
         h->phase_us[i] = std::chrono::duration<double, std::micro>(now - from).count();
@@ -553,7 +642,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
             if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
             const int grid = (n_groups + 3) / 4;  // one wave per group
             hipLaunchKernelGGL(detect_row_blocks, dim3(grid), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx, M, (int32_t)h->nnz,
-                               (int32_t)h->block_min_len, (int32_t)h->long_thr, h->d_blk_flag);
+                               (int32_t)h->block_min_len, detect_max, h->d_blk_flag);
             hipError_t e = hipGetLastError();
             std::vector<uint8_t> flags((size_t)n_groups);
             if (e == hipSuccess) e = hipMemcpy(flags.data(), h->d_blk_flag, (size_t)n_groups, hipMemcpyDeviceToHost);
@@ -597,8 +686,8 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         for (int32_t r = 0; r < M; ++r) {
             const int32_t beg = ptr[r], end = ptr[r + 1], len = end - beg;
             if (len <= mthr) continue;
+            if (!flags_host.empty() && flags_host[(size_t)(r >> 4)]) continue;      // block path owns it, whatever its length
             if (len <= thr) {
-                if (!flags_host.empty() && flags_host[(size_t)(r >> 4)]) continue;  // block path owns it
                 Chunk c;
                 c.beg = beg;
                 c.end = end;
@@ -610,9 +699,15 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
             }
             LongRow L;
             L.row = r;
+            L.len = len;
+            if (!h->split_long) {      // exact order: the hub kernel walks the row whole
+                L.first_slot = -1;
+                L.n_chunks = 0;
+                longs.push_back(L);
+                continue;
+            }
             L.first_slot = n_slots;
             L.n_chunks = 0;
-            L.pad = 0;
             for (int32_t b = beg; b < end; b += (end - b > clen ? clen : end - b)) {
                 Chunk c;
                 c.beg = b;
@@ -624,6 +719,8 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
             }
             longs.push_back(L);
         }
+        // hub rows longest first, ties in row order (as the device builder's stable radix sort leaves them)
+        std::stable_sort(longs.begin(), longs.end(), [](const LongRow &x, const LongRow &y) { return x.len > y.len; });
         // longest first, stable: counting sort on the length (<= max(long_thr, long_chunk) by construction)
         int32_t lmax = 0;
         for (const Chunk &c : chunks) lmax = std::max(lmax, c.end - c.beg);
@@ -641,16 +738,16 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)n_medium;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
     lap(3, tp);
-    if (h->n_chunks > 0) {
+    if (h->n_chunks > 0 || h->n_long > 0) {
         const size_t cb = chunks.size() * sizeof(Chunk), lb = longs.size() * sizeof(LongRow);
         const size_t pb = (size_t)n_slots * (size_t)h->ldp * sizeof(float);
-        if (hipMalloc((void **)&h->d_chunks, cb) != hipSuccess ||
+        if (hipMalloc((void **)&h->d_chunks, cb ? cb : 16) != hipSuccess ||
             hipMalloc((void **)&h->d_long, lb ? lb : 16) != hipSuccess ||
-            hipMalloc((void **)&h->d_partials, pb ? pb : 16) != hipSuccess) {
+            (pb && hipMalloc((void **)&h->d_partials, pb) != hipSuccess)) {
             free_plan(h);
             return MI_SPMM_ENOMEM;
         }
-        hipError_t e = hipMemcpy(h->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice);
+        hipError_t e = cb ? hipMemcpy(h->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice) : hipSuccess;
         if (e == hipSuccess && lb) e = hipMemcpy(h->d_long, longs.data(), lb, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             free_plan(h);
@@ -663,6 +760,10 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         if (brc != 0) { free_plan(h); return brc; }
     }
     lap(4, tp);
+    {
+        const int src = ensure_side_streams(h);
+        if (src != 0) { free_plan(h); return src; }
+    }
     h->prepared = true;
     h->preprocess_us =
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -757,6 +858,22 @@ void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 g
     else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s); else launch_block_items_g<1, false, false>(slab, a, grid, s); }
 }
 
+template <bool WIDE>
+void launch_hub2(int sw, const HubArgs &a, dim3 grid, hipStream_t s)
+{
+    if (sw == 16) hipLaunchKernelGGL((spmm_hub2<16, WIDE>), grid, dim3(64 * (1 + Hub2Cfg<16>::L)), 0, s, a);
+    else if (sw == 64) hipLaunchKernelGGL((spmm_hub2<64, WIDE>), grid, dim3(64 * (1 + Hub2Cfg<64>::L)), 0, s, a);
+    else hipLaunchKernelGGL((spmm_hub2<32, WIDE>), grid, dim3(64 * (1 + Hub2Cfg<32>::L)), 0, s, a);
+}
+
+template <bool WIDE>
+void launch_hub(int sw, const HubArgs &a, dim3 grid, hipStream_t s)
+{
+    if (sw == 16) hipLaunchKernelGGL((spmm_hub<16, WIDE>), grid, dim3(64), 0, s, a);
+    else if (sw == 64) hipLaunchKernelGGL((spmm_hub<64, WIDE>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((spmm_hub<32, WIDE>), grid, dim3(64), 0, s, a);
+}
+
 // Column-tile width of the rows / segment kernels when the caller leaves it to us (profiles/r02_wide_n_tiles.txt):
 //   columns near the row's own position (banded / mesh / community structure): whole-wave tiles -- neighbouring rows
 //     share B rows through L2 and a narrower tile only re-reads A (banded N=256: 1.75 ms at 256, 1.88 at 128, 2.15 at 64);
@@ -836,7 +953,39 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     const int pol = (h->nt_store ? kPolNtStore : 0) | (h->nt_stream ? kPolNtStream : 0);
     int launches = 0;
 
-    // segment, block and reduce kernels walk their whole tables and keep the rows of this call's range
+    // segment, hub, block and reduce kernels walk their whole tables and keep the rows of this call's range.
+    // The hub kernel goes first (its longest row is the step's longest dependent chain) and, like the block kernel,
+    // addresses the full width: it is launched with the first column part only.
+    if (h->n_long > 0 && !h->split_long && launch_blocks_here) {
+        HubArgs ha;
+        ha.rows = h->d_long;
+        ha.row_ptr = h->d_ptr;
+        ha.col_idx = h->d_idx;
+        ha.vals = h->d_val;
+        ha.B = full.B;
+        ha.C = full.C;
+        ha.ldb = ldb;
+        ha.ldc = ldc;
+        ha.n_hubs = h->n_long;
+        ha.N = full.N;
+        ha.row_lo = row_begin;
+        ha.row_hi = row_end;
+        const int sw = h->hub_slice > 0 ? (int)h->hub_slice : (full.N <= 16 ? 16 : 32);
+        const bool wide_hub = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
+                                ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
+        const int slices = (full.N + sw - 1) / sw;
+        if ((int64_t)slices * h->n_long > INT32_MAX) return MI_SPMM_EUNSUPPORTED;
+        ha.slices = slices;
+        dim3 hgrid((unsigned)(slices * h->n_long));
+        hipStream_t hs = s;
+        {
+            const int fr = side_stream(h, 0, s, &hs);
+            if (fr != 0) return fr;
+        }
+        if (h->hub_kernel == 1) { if (wide_hub) launch_hub<true>(sw, ha, hgrid, hs); else launch_hub<false>(sw, ha, hgrid, hs); }
+        else { if (wide_hub) launch_hub2<true>(sw, ha, hgrid, hs); else launch_hub2<false>(sw, ha, hgrid, hs); }
+        ++launches;
+    }
     if (h->n_chunks > 0) {
         ChunkArgs ca;
         ca.chunks = h->d_chunks;
@@ -857,8 +1006,15 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         dim3 cgrid((h->n_chunks + cgpb - 1) / cgpb, col_tiles);
         // partial rows are ldp (multiple of 4) floats and hipMalloc-aligned, so only
         // the B side decides the vector width here
-        if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, s); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, s, (int)h->segment_unroll); }
-        else { if (wide) launch_chunks_lpr<1, true>(lpr, ca, cgrid, s); else launch_chunks_lpr<1, false>(lpr, ca, cgrid, s); }
+        // on side stream 1: a segment is one lane group's dependent chain (up to long_row_threshold nonzeros), and the rows
+        // kernel behind it in the same stream would wait for the longest one
+        hipStream_t cs = s;
+        {
+            const int fr = side_stream(h, 1, s, &cs);
+            if (fr != 0) return fr;
+        }
+        if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, cs, (int)h->segment_unroll); }
+        else { if (wide) launch_chunks_lpr<1, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<1, false>(lpr, ca, cgrid, cs); }
         ++launches;
     }
 
@@ -920,7 +1076,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     else launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
     if (rows_needed) ++launches;
 
-    if (h->n_long > 0) {
+    if (h->n_long > 0 && h->split_long) {
         ReduceArgs ra;
         ra.rows = h->d_long;
         ra.partials = h->d_partials + col0;
@@ -934,8 +1090,13 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ra.row_hi = row_end;
         const int64_t threads = (int64_t)h->n_long * ((N + V - 1) / V);
         dim3 rgrid((unsigned)((threads + kBlockThreads - 1) / kBlockThreads));
-        if (vec4) hipLaunchKernelGGL((spmm_reduce_chunks<4>), rgrid, dim3(kBlockThreads), 0, s, ra);
-        else hipLaunchKernelGGL((spmm_reduce_chunks<1>), rgrid, dim3(kBlockThreads), 0, s, ra);
+        hipStream_t cs = s;       // behind the segment kernel that produced the partial sums
+        {
+            const int fr = side_stream(h, 1, s, &cs);
+            if (fr != 0) return fr;
+        }
+        if (vec4) hipLaunchKernelGGL((spmm_reduce_chunks<4>), rgrid, dim3(kBlockThreads), 0, cs, ra);
+        else hipLaunchKernelGGL((spmm_reduce_chunks<1>), rgrid, dim3(kBlockThreads), 0, cs, ra);
         ++launches;
     }
     if (record) {
@@ -972,10 +1133,18 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     int32_t rem = (h->split_cols && N > 256) ? N % 256 : 0;
     if (rem > 64) rem = 0;
     int launches = 0;
+    h->fork_recorded = h->forked[0] = h->forked[1] = false;
     int rc = run_part(h, d_vin, ldb, d_vout, ldc, row_begin, row_end, s, N - rem, 0, blocks_on, true, full, &launches, true);
     if (rc == 0 && rem > 0)
         rc = run_part(h, d_vin + (N - rem), ldb, d_vout + (N - rem), ldc, row_begin, row_end, s, rem, N - rem, blocks_on,
                       false, full, &launches, false);
+    for (int i = 0; i < 2; ++i) {      // join: whatever the caller enqueues next is ordered after the side streams' rows too
+        if (!h->forked[i]) continue;
+        h->forked[i] = false;
+        hipError_t je = hipEventRecord(h->ev_join[i], h->side[i]);
+        if (je == hipSuccess) je = hipStreamWaitEvent(s, h->ev_join[i], 0);
+        if (rc == 0 && je != hipSuccess) rc = (int)je;
+    }
     h->last_launches = launches;
     return rc;
 }

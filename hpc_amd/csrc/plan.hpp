@@ -10,19 +10,47 @@
 
 namespace mi {
 
+// ---- auto hub threshold of the default (exact-order) mode ------------------------------------------------------
+// Two kernels take rows in stored order: the segment kernel (one lane group per row, 32 gathers in flight: 47 ns per
+// nonzero of ONE row on an idle chip, ~200 ns beside a rows kernel that saturates the fabric; but thousands of rows at
+// once, i.e. full memory throughput) and the hub kernel (6.5 ns per nonzero of one row, about half the segment kernel's
+// throughput).  So: a row becomes a hub when, as a segment on its side stream, it could no longer hide behind the rest of
+// the step -- L x 200 ns > half the step's estimated time (gather-model bytes at 6 TB/s) -- unless the rows above that
+// length hold more than a quarter of all nonzeros: then the hub kernel would carry the step at its lower throughput, and the
+// threshold moves up until they do not (ddi-shaped graphs: every row is long).  Candidates 256 .. 8192, powers of two.
+// Measured against fixed thresholds on eight graph shapes x three widths: profiles/r03_hub_thresholds.txt.
+// The histogram comes from the same pass over row_ptr that finds the longest row; both plan builders use this function.
+constexpr int kHistN = 6;
+__host__ __device__ inline int32_t hist_threshold(int i) { return 256 << i; }
+struct LenHist {
+    uint32_t cnt[kHistN];             // rows longer than hist_threshold(i)
+    unsigned long long nnz[kHistN];   // ... and the nonzeros they hold
+};
+__host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M, int32_t N, const unsigned long long *nnz_above)
+{
+    const double bytes = (double)nnz * (4.0 * N + 8.0) + 4.0 * (double)M * N;
+    const double t = 0.5 * (bytes / 6e12) / 200e-9;
+    int i = 0;
+    while (i + 1 < kHistN && (double)hist_threshold(i + 1) <= t) ++i;
+    while (i + 1 < kHistN && (double)nnz_above[i] > 0.25 * (double)nnz) ++i;
+    return hist_threshold(i);
+}
+
 struct PlanOut {
     Chunk *d_chunks = nullptr;      // [n_chunks], sorted by length descending (stable in row order)
-    LongRow *d_long = nullptr;      // [n_long]
+    LongRow *d_long = nullptr;      // [n_long], longest first (stable in row order)
     int32_t *d_blk_groups = nullptr;  // [n_blk_groups] (only when d_blk_flag was given)
     int32_t n_chunks = 0, n_long = 0, n_slots = 0, n_medium = 0, n_blk_groups = 0;
     int32_t max_len = 0;
     int32_t mthr = 0;               // resolved medium threshold (the rows kernel skips rows above it)
+    int32_t thr = 0;                // resolved hub threshold (the caller's value, or the auto rule above)
     int32_t local_pct = 0;          // sampled nonzeros within a window of their row's own position, percent (column-tile rule)
 };
 
 // Returns 0, a negative MI_SPMM_E* code (malformed CSR, out of memory) or a positive hipError_t.
 // d_blk_flag: per 16-row group, 1 = block path owns it (nullable).  col_bad: device flag written
 // by csr_check_cols earlier on the same (null) stream; read back with the same single copy.
+// split: 1 = hubs are cut into pieces of clen (summed piece by piece), 0 = hubs are only listed (spmm_hub keeps their order).
 // mthr: medium threshold, 0 = auto (resolved on the device from the longest row, returned in PlanOut::mthr).
 // A grow-only device arena owned by the handle: preprocess temporaries are carved out of it.
 struct Scratch {
@@ -32,7 +60,10 @@ struct Scratch {
 int scratch_reserve(Scratch *s, size_t bytes);   // 0 or MI_SPMM_ENOMEM; contents are lost when it grows
 void scratch_release(Scratch *s);
 
-int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, const uint8_t *d_blk_flag,
-                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, Scratch *sa, Scratch *sb, PlanOut *out);
+// thr: hub threshold, 0 = auto (exact mode only; resolved on the device from the row-length histogram, returned in PlanOut::thr).
+// N: dense width (the auto rule's byte estimate).
+int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int32_t N, int64_t nnz,
+                   const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, int32_t split,
+                   Scratch *sa, Scratch *sb, PlanOut *out);
 
 }  // namespace mi

@@ -14,11 +14,11 @@ struct Chunk {              // one segment of one row, handled by one lane group
     int32_t row;            // CSR row it belongs to
 };
 
-struct LongRow {
+struct LongRow {            // a row longer than the split threshold (a hub)
     int32_t row;
-    int32_t first_slot;
-    int32_t n_chunks;
-    int32_t pad;
+    int32_t first_slot;     // split mode: its pieces' partial sums are slots [first_slot, first_slot + n_chunks); hub mode: -1
+    int32_t n_chunks;       // split mode: number of pieces; hub mode (exact order, spmm_hub): 0
+    int32_t len;            // nonzeros in the row
 };
 
 // ---- block (MFMA) path ---------------------------------------------------------------------------

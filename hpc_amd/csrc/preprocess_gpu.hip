@@ -23,11 +23,14 @@ struct PlanStats {
     int32_t n_groups_selected;
     int32_t mthr;      // resolved medium threshold (auto rule below, or the caller's value), already capped by thr
     int32_t near, sampled;   // column locality sample: nonzeros of sampled rows whose column lies near the row's own position
+    int32_t thr;       // resolved hub threshold (the caller's value or resolve_hub_threshold)
+    int32_t pad;
+    LenHist hist;      // rows above 256 .. 8192 nonzeros and what they hold (the auto hub threshold reads it)
 };
 
 __global__ void init_plan_stats(PlanStats *stats)
 {
-    if (threadIdx.x == 0) *stats = PlanStats{0, 0u, 0, 0, 0, 0, 0, 0};
+    if (threadIdx.x == 0) *stats = PlanStats{};
 }
 
 // Column locality of a row sample: how many nonzeros sit within `window` columns of their row's own position
@@ -64,7 +67,21 @@ __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *
 __global__ __launch_bounds__(kBlockThreads) void row_len_max(const int32_t *__restrict__ row_ptr, int32_t M, PlanStats *stats)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
-    int m = (r < M) ? row_ptr[r + 1] - row_ptr[r] : 0;
+    const int len = (r < M) ? row_ptr[r + 1] - row_ptr[r] : 0;
+    // rows above 256, 512, ... 8192 nonzeros: count and content, one pair of atomics per wave and threshold that has any
+#pragma unroll
+    for (int i = 0; i < kHistN; ++i) {
+        const bool above = len > hist_threshold(i);
+        const unsigned long long mask = __ballot(above);
+        if (mask == 0) break;                              // wave-uniform; a longer threshold has none either
+        unsigned long long part = above ? (unsigned long long)len : 0ull;
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats->hist.cnt[i], (uint32_t)__builtin_popcountll(mask));
+            atomicAdd(&stats->hist.nnz[i], part);
+        }
+    }
+    int m = len;
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
     // one same-address atomic per wave was most of this kernel's time (16 K waves): skip it unless it can raise the max
     if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&stats->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -82,7 +99,8 @@ __device__ __forceinline__ int resolve_mthr(int mthr_user, int mean_len, int max
 
 __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__restrict__ row_ptr, int32_t M,
                                                               const uint8_t *__restrict__ blk_flag, int32_t mthr_user,
-                                                              int32_t mean_len, int32_t thr, int32_t clen,
+                                                              int32_t mean_len, int32_t thr_user, int32_t clen, int32_t split,
+                                                              int64_t nnz, int32_t N,
                                                               int32_t *__restrict__ seg_cnt,
                                                               int32_t *__restrict__ slot_cnt,
                                                               int32_t *__restrict__ long_cnt, PlanStats *stats)
@@ -90,24 +108,28 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
     const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
     int len = 0;
     unsigned bad = 0;
-    const int mthr = resolve_mthr(mthr_user, mean_len, stats->max_len, thr);   // max_len: complete (previous kernel)
+    // max_len and the histogram are complete (previous kernel); every thread resolves the same two thresholds
+    const int thr = thr_user > 0 ? thr_user : resolve_hub_threshold(nnz, M, N, stats->hist.nnz);
+    const int mthr = resolve_mthr(mthr_user, mean_len, stats->max_len, thr);
     if (r < M) {
         const int beg = row_ptr[r], end = row_ptr[r + 1];
         len = end - beg;
         if (len < 0) { bad = 1; len = 0; }
         int segs = 0, slots = 0, lng = 0;
-        if (len > mthr) {
+        if (len > mthr && !(blk_flag && blk_flag[r >> 4])) {   // (a 16-row group the block path took stays with it, whatever its length)
             if (len <= thr) {
-                if (!(blk_flag && blk_flag[r >> 4])) segs = 1;   // medium row: one exact segment
+                segs = 1;                                        // medium row: one exact segment
             } else {
-                segs = slots = 1 + (len - 1) / clen;            // hub: pieces + partial-sum slots (len > thr >= 1; no int32 overflow)
+                // hub.  split mode: pieces + partial-sum slots (len > thr >= 1; no int32 overflow); default: no segment
+                // at all -- the hub kernel walks the row in stored order
+                if (split) segs = slots = 1 + (len - 1) / clen;
                 lng = 1;
             }
         }
         seg_cnt[r] = segs;
         slot_cnt[r] = slots;
         long_cnt[r] = lng;
-        if (r == 0) { stats->ptr0 = beg; stats->mthr = mthr; if (beg < 0) bad |= 2; }
+        if (r == 0) { stats->ptr0 = beg; stats->mthr = mthr; stats->thr = thr; if (beg < 0) bad |= 2; }
         if (r == M - 1) stats->ptrM = end;
     } else if (r == M) {   // trailing zero so the exclusive scans leave the totals at index M
         seg_cnt[r] = 0;
@@ -124,15 +146,16 @@ __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__
                                                               const int32_t *__restrict__ slot_off,
                                                               const int32_t *__restrict__ long_off,
                                                               Chunk *__restrict__ chunks, uint32_t *__restrict__ keys,
-                                                              LongRow *__restrict__ longs)
+                                                              LongRow *__restrict__ longs, uint32_t *__restrict__ long_keys)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
     if (r >= M) return;
     const int n = seg_cnt[r];
-    if (n == 0) return;
     const int beg = row_ptr[r], end = row_ptr[r + 1];
-    int o = seg_off[r];
-    if (end - beg <= thr) {
+    const bool hub = long_off[r + 1] != long_off[r];       // classified as one (a long row of a block group is not)
+    if (!hub) {
+        if (n == 0) return;
+        const int o = seg_off[r];
         Chunk c;
         c.beg = beg;
         c.end = end;
@@ -142,13 +165,17 @@ __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__
         keys[o] = (uint32_t)(end - beg);
         return;
     }
+    // a hub: listed in either mode (n == 0: the hub kernel takes the row whole; n > 0: its pieces follow)
+    int o = seg_off[r];
     int slot = slot_off[r];
     LongRow L;
     L.row = (int32_t)r;
-    L.first_slot = slot;
+    L.first_slot = n > 0 ? slot : -1;
     L.n_chunks = n;
-    L.pad = 0;
+    L.len = end - beg;
     longs[long_off[r]] = L;
+    long_keys[long_off[r]] = (uint32_t)(end - beg);
+    if (n == 0) return;
     for (int b = beg; b < end; b += (end - b > clen ? clen : end - b), ++o, ++slot) {
         Chunk c;
         c.beg = b;
@@ -203,11 +230,13 @@ void scratch_release(Scratch *s)
 
 #define PLAN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (e_ == hipErrorOutOfMemory) ? MI_SPMM_ENOMEM : (int)e_; } while (0)
 
-int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, const uint8_t *d_blk_flag,
-                   const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, Scratch *sa, Scratch *sb, PlanOut *out)
+int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int32_t N, int64_t nnz,
+                   const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr_user, int32_t clen, int32_t split,
+                   Scratch *sa, Scratch *sb, PlanOut *out)
 {
     *out = PlanOut();
-    out->mthr = (mthr > 0 ? mthr : 64) < thr ? (mthr > 0 ? mthr : 64) : thr;   // replaced by the device's value below
+    out->thr = thr_user > 0 ? thr_user : 256;                                   // both replaced by the device's values below
+    out->mthr = (mthr > 0 ? mthr : 64) < out->thr ? (mthr > 0 ? mthr : 64) : out->thr;
     if (M <= 0) return (nnz == 0) ? MI_SPMM_OK : MI_SPMM_ECSR;
     const size_t n1 = (size_t)M + 1;
     const int n_groups_all = (M + 15) / 16;
@@ -247,7 +276,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                            d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
     }
     hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
-                       (int32_t)(nnz / M), thr, clen, seg_cnt, slot_cnt, long_cnt, stats);
+                       (int32_t)(nnz / M), thr_user, clen, split, nnz, N, seg_cnt, slot_cnt, long_cnt, stats);
     PLAN_TRY(hipGetLastError());
     size_t t = tb;
     PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, t, seg_cnt, seg_off, (int)n1));
@@ -279,6 +308,8 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     }
     out->max_len = host.st.max_len;
     out->mthr = host.st.mthr;
+    out->thr = host.st.thr;
+    const int32_t thr = host.st.thr;
     out->local_pct = host.st.sampled > 0 ? (int32_t)(100.0 * host.st.near / host.st.sampled) : 0;
     out->n_chunks = host.n_chunks;
     out->n_slots = host.n_slots;
@@ -291,21 +322,31 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
         PLAN_TRY(hipMalloc((void **)&out->d_blk_groups, (size_t)ng * sizeof(int32_t)));
         PLAN_TRY(hipMemcpyAsync(out->d_blk_groups, groups, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToDevice, 0));
     }
-    if (host.n_chunks > 0) {
-        const size_t n = (size_t)host.n_chunks;
+    if (host.n_chunks > 0 || host.n_long > 0) {
+        const size_t n = (size_t)host.n_chunks, nl = (size_t)host.n_long;
         int end_bit = 1;
         while (end_bit < 32 && (host.st.max_len >> end_bit)) ++end_bit;
-        size_t sbytes = 0;
-        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sbytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (Chunk *)nullptr,
-                                                              (Chunk *)nullptr, (int)n, 0, end_bit));
+        // segments longest first; hub rows longest first (the hub kernel's tail is its longest row: start it first).
+        // Both sorts are stable: equal lengths stay in row order.
+        size_t sbytes = 0, lbytes = 0;
+        if (n > 0)
+            PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sbytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (Chunk *)nullptr,
+                                                                  (Chunk *)nullptr, (int)n, 0, end_bit));
+        if (nl > 0)
+            PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, lbytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (LongRow *)nullptr,
+                                                                  (LongRow *)nullptr, (int)nl, 0, end_bit));
         Chunk *unsorted = nullptr;
-        uint32_t *keys_in = nullptr, *keys_out = nullptr;
+        LongRow *longs_unsorted = nullptr;
+        uint32_t *keys_in = nullptr, *keys_out = nullptr, *lkeys_in = nullptr, *lkeys_out = nullptr;
         char *tmp2 = nullptr;
         auto layout_b = [&](Carver &c) {
             unsorted = c.take<Chunk>(n);
             keys_in = c.take<uint32_t>(n);
             keys_out = c.take<uint32_t>(n);
-            tmp2 = c.take<char>(sbytes);
+            longs_unsorted = c.take<LongRow>(nl);
+            lkeys_in = c.take<uint32_t>(nl);
+            lkeys_out = c.take<uint32_t>(nl);
+            tmp2 = c.take<char>(sbytes > lbytes ? sbytes : lbytes);
         };
         {
             Carver dry(nullptr);
@@ -315,13 +356,14 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
             Carver real(sb->p);
             layout_b(real);
         }
-        PLAN_TRY(hipMalloc((void **)&out->d_chunks, n * sizeof(Chunk)));
-        PLAN_TRY(hipMalloc((void **)&out->d_long, (host.n_long > 0 ? (size_t)host.n_long : 1) * sizeof(LongRow)));
+        PLAN_TRY(hipMalloc((void **)&out->d_chunks, (n > 0 ? n : 1) * sizeof(Chunk)));
+        PLAN_TRY(hipMalloc((void **)&out->d_long, (nl > 0 ? nl : 1) * sizeof(LongRow)));
         hipLaunchKernelGGL(emit_segments, dim3((unsigned)(((size_t)M + kBlockThreads - 1) / kBlockThreads)),
                            dim3(kBlockThreads), 0, 0, d_row_ptr, M, thr, clen, seg_cnt, seg_off, slot_off, long_off,
-                           unsorted, keys_in, out->d_long);
+                           unsorted, keys_in, longs_unsorted, lkeys_in);
         PLAN_TRY(hipGetLastError());
-        PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
+        if (n > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
+        if (nl > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, lbytes, lkeys_in, lkeys_out, longs_unsorted, out->d_long, (int)nl, 0, end_bit));
     }
     PLAN_TRY(hipStreamSynchronize(0));
     return MI_SPMM_OK;

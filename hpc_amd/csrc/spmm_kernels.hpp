@@ -402,6 +402,402 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
     Vec<V>::template store<true>(a.C + (int64_t)L.row * a.ldc + col, acc);
 }
 
+// ---- hub kernel: rows longer than the split threshold, in STORED ORDER, fed through an LDS ring ---------------
+// A hub row is one fma chain per output column, tens of thousands of terms long.  The segment kernel above keeps at
+// most 32 B-row gathers in flight per chain (registers), i.e. ~47 ns per nonzero: a 64 K-nonzero hub alone would take
+// 3 ms.  Cutting the row into pieces (spmm_chunks + spmm_reduce_chunks, still available as "split_long_rows" = 1)
+// parallelises it but changes the summation order.  Here the order stays and the memory latency leaves the chain:
+//   * one WAVE per (hub row, slice of SW columns); the N/SW slices of a row are independent chains on different CUs;
+//   * everything the wave reads arrives by LDS-DMA (global_load_lds, no VGPR destination): per stage of 64 nonzeros
+//     one dword DMA for col_idx, one for vals and Q = 64*SW*4/1024 sixteen-byte DMAs for the B-row slices (lane l of
+//     instruction q fetches part l % (SW/4) of nonzero q*NPI + l / (SW/4): whole 64..256-byte row segments);
+//   * D stages of B rows are in flight at any time -- up to 63 wave-instructions, 56 KiB, 448 nonzeros at SW = 32 --
+//     where registers hold 32; the (col, val) pairs run a further D stages ahead because a stage's B addresses
+//     need its columns (read back from LDS);
+//   * the wave waits with a COUNTED s_waitcnt vmcnt (vector-memory operations retire in issue order): "all but the
+//     youngest (D-1) stages' worth" -- never vmcnt(0) inside the loop; hipcc does not see the DMA (inline asm), so no
+//     compiler-generated wait drains the ring, and the loop contains no other vector-memory instruction;
+//   * the chain itself: lane j owns column j of the slice, reads B[k][j] with ds_read_b32 and the value a_k as a
+//     broadcast ds_read_b128 (4 values), one v_fma_f32 per nonzero, k ascending: bit-identical to spmm_ref.cu:10-14.
+// Rate: ~4-5 ns per nonzero and slice against 47 (measured: profiles/r03_hub_*), the slices of a row in parallel.
+struct HubArgs {
+    const LongRow *rows;     // hub rows, longest first
+    const int32_t *row_ptr;
+    const int32_t *col_idx;
+    const float *vals;
+    const float *B;
+    float *C;
+    int64_t ldb;
+    int64_t ldc;
+    int32_t n_hubs;
+    int32_t N;
+    int32_t slices;          // ceil(N / SW); gridDim.x = slices * n_hubs
+    int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are skipped (row panels)
+};
+
+// One wave-instruction of LDS-DMA: lane l's bytes land at lds_dst + 16 l (4 l for the dword form).  M0 carries the LDS
+// address; it is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(uint32_t lds_dst, const void *sbase, uint32_t voff)   // SGPR base + 32-bit lane offset
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void glds16w(uint32_t lds_dst, const void *addr)                  // 64-bit lane address
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(addr), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void glds4w(uint32_t lds_dst, const void *addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(addr), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int SW> struct HubCfg {
+    static constexpr int ST = 64;                  // nonzeros per stage
+    static constexpr int NPI = 256 / SW;           // nonzeros per B DMA instruction (64 lanes x 16 B = NPI slices of SW floats)
+    static constexpr int Q = ST / NPI;             // B DMA instructions per stage (SW 16 / 32 / 64: 4 / 8 / 16)
+    static constexpr int PER = Q + 2;              // ... plus the stage's col_idx and vals
+    static constexpr int D = SW == 64 ? 4 : SW == 32 ? 7 : 11;   // stages of B rows in flight: (D - 1) * PER <= 63, the widest counted wait
+    static constexpr int NB = D + 1;               // B ring: stage t is consumed while stage t + D lands
+    static constexpr int NP = 2 * D + 1;           // pair ring: pairs run 2 D stages ahead
+    static constexpr int B_BYTES = ST * SW * 4;
+    static constexpr int P_BYTES = 512;            // 64 columns, then 64 values
+    static constexpr int LDS_BYTES = NB * B_BYTES + NP * P_BYTES;
+    static_assert((D - 1) * PER <= 63, "vmcnt is a 6-bit counter");
+};
+
+// s_waitcnt vmcnt(BASE + STEP * r) for a wave-uniform r in [0, RMAX]: the immediate must be a constant
+template <int BASE, int STEP, int R> __device__ __forceinline__ void wait_vm_counted(int r)
+{
+    if constexpr (R == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+    else {
+        if (r == R) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + STEP * R) : "memory");
+        else wait_vm_counted<BASE, STEP, R - 1>(r);
+    }
+}
+
+template <int SW, bool WIDE>
+__global__ __launch_bounds__(64) void spmm_hub(HubArgs a)
+{
+    typedef HubCfg<SW> K;
+    constexpr int D = K::D, NB = K::NB, NP = K::NP, Q = K::Q, NPI = K::NPI;
+    constexpr int LPS = SW / 4;                    // lanes (16-byte parts) per row slice
+    __shared__ __attribute__((aligned(16))) unsigned char ring[K::LDS_BYTES];   // ONE array: B stages, then pair stages
+    const int lane = threadIdx.x;
+    const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;   // the slices of one hub are neighbours in dispatch order
+    const int row = __builtin_amdgcn_readfirstlane(a.rows[hub].row);
+    if (row < a.row_lo || row >= a.row_hi) return;
+    const int beg = __builtin_amdgcn_readfirstlane(a.row_ptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(a.row_ptr[row + 1]);
+    const int len = end - beg;
+    if (len <= 0) return;                          // (hub rows are long; an empty one would have nothing to clamp to)
+    const int n_st = (len + K::ST - 1) / K::ST;
+    // loader role of this lane: 16-byte part `part` of nonzero `ni` of each B instruction.  A slice that sticks out past
+    // N (or a width that is no multiple of 4) shifts its last parts back to column N - 4: they re-fetch and recompute
+    // columns of their neighbours with identical bits (as in the rows kernel).
+    const int part = lane % LPS, ni = lane / LPS;
+    const int colf = min(slice * SW + 4 * part, a.N - 4);
+    const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colf * 4u;
+    const uint32_t lds_b = (uint32_t)(size_t)&ring[0];                 // low 32 bits of a shared-aperture address = the LDS offset
+    const uint32_t lds_p = lds_b + NB * K::B_BYTES;
+
+    auto issue_pairs = [&](int s) {                // stage s: its 64 columns and 64 values (past the row: the last pair again)
+        const int k = min(beg + K::ST * s + lane, end - 1);
+        const uint32_t dst = lds_p + (uint32_t)(s % NP) * K::P_BYTES;
+        glds4w(dst, a.col_idx + k);
+        glds4w(dst + 256, a.vals + k);
+    };
+    auto issue_b = [&](int s) {                    // stage s: its 64 B-row slices (needs the stage's columns in LDS)
+        const int32_t *cols = reinterpret_cast<const int32_t *>(&ring[NB * K::B_BYTES + (s % NP) * K::P_BYTES]);
+        const uint32_t dst = lds_b + (uint32_t)(s % NB) * K::B_BYTES;
+        int c[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c[q] = cols[q * NPI + ni];     // all LDS reads first: one wait, not one per DMA
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (WIDE) glds16w(dst + q * 1024, a.B + (int64_t)c[q] * a.ldb + colf);
+            else glds16(dst + q * 1024, a.B, __umul24((uint32_t)c[q], ldb_bytes) + col_bytes);
+        }
+    };
+
+    // consumer role: lane j (mod SW) owns column j of the slice
+    const int cj = lane % SW;
+    float acc = 0.f;
+    auto consume = [&](int s, int cnt) {
+        const float *bs = reinterpret_cast<const float *>(&ring[(s % NB) * K::B_BYTES]) + cj;
+        const float *vs = reinterpret_cast<const float *>(&ring[NB * K::B_BYTES + (s % NP) * K::P_BYTES + 256]);
+        if (cnt == K::ST) {
+            // every LDS read of the stage first (64 values of this lane's column, 16 broadcast quads of a), then the 64
+            // dependent fmas with counted waits: one exposed LDS latency per stage
+            float b[K::ST];
+            float4v av[K::ST / 4];
+#pragma unroll
+            for (int u = 0; u < K::ST; ++u) b[u] = bs[u * SW];
+#pragma unroll
+            for (int i = 0; i < K::ST / 4; ++i) av[i] = *reinterpret_cast<const float4v *>(vs + 4 * i);
+#pragma unroll
+            for (int u = 0; u < K::ST; ++u) acc = __builtin_fmaf(b[u], av[u / 4][u % 4], acc);
+        } else {
+            for (int i = 0; i < cnt; ++i) acc = __builtin_fmaf(bs[i * SW], vs[i], acc);
+        }
+    };
+
+    // prologue: the pairs of stages 0 .. D-1, one full round trip, then -- as pseudo-iterations -D .. -1 of the loop
+    // below -- the pairs of stages D .. 2D-1 and the B rows of stages 0 .. D-1
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue_pairs(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int s = 0; s < D; ++s) {
+        issue_pairs(s + D);
+        if (s < n_st) issue_b(s);
+    }
+    for (int t = 0; t < n_st; ++t) {
+        // Iteration j issued 2 pair instructions and, if stage j + D exists, Q B instructions.  Everything iteration
+        // t - D issued (B rows of stage t, pairs of stage t + D) must have landed; iterations t-D+1 .. t-1 may be in flight.
+        const int r = min(D - 1, n_st - 1 - t);
+        wait_vm_counted<2 * (D - 1), Q, D - 1>(r);
+        issue_pairs(t + 2 * D);
+        if (t + D < n_st) issue_b(t + D);
+        consume(t, min(K::ST, len - K::ST * t));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the wave has gone (the LDS would be someone else's)
+    if (lane < SW) {
+        const int col = min(slice * SW + 4 * (cj / 4), a.N - 4) + (cj & 3);
+        __builtin_nontemporal_store(acc, a.C + (int64_t)row * a.ldc + col);
+    }
+}
+
+// ---- hub kernel, second form: loader waves + one chain wave ---------------------------------------------------
+// spmm_hub (above) spends ~28 cycles per nonzero: the wave that runs the chain also issues ten LDS-DMA instructions
+// per 64 nonzeros (~90 cycles each with a deep queue) and needs 0.75 LDS reads per nonzero, because an LDS-DMA lands
+// a B row as it is ([k][column]: a lane's next value sits in another 16-byte granule).  Here a workgroup is ONE chain
+// wave and L loader waves:
+//   * a loader takes every L-th stage of 64 nonzeros: B-row slices by ordinary 16-byte global loads, U stages deep in
+//     registers (L x U x 8 KiB in flight per workgroup), and writes them to the LDS ring TRANSPOSED -- four loads of one
+//     lane are nonzeros k..k+3 of the same four columns, so a 4 x 4 register transpose (free: register naming) turns
+//     them into one ds_write_b128 per column: ring[column][k..k+3];
+//   * the chain wave owns one column per lane: ONE ds_read_b128 brings its next four B values, one broadcast
+//     ds_read_b128 the four a values: 0.5 LDS reads and one v_fma_f32 per nonzero, k ascending -- the same chain,
+//     bit for bit, as spmm_ref.cu:10-14;
+//   * hand-off through two kinds of LDS words: published[w] = stages loader w has written (loader -> chain wave) and done = stages consumed
+//     (chain wave -> loaders, so a slot is not overwritten early).  A wave's LDS operations execute in order, so a
+//     flag written after the data is seen after the data; no barrier inside the loop, one at kernel start.
+// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, the loaders' writes 2-way.
+template <int SW> struct Hub2Cfg {
+    static constexpr int ST = 64;                  // nonzeros per stage
+    static constexpr int L = 3;                    // loader waves
+    static constexpr int U = 3;                    // stages each loader holds in registers
+    static constexpr int LPS = SW / 4;             // lanes (16-byte parts) per row slice = loads per stage and lane
+    static constexpr int NG = 64 / LPS;            // nonzero groups per load instruction
+    static constexpr int NBK = ST / (4 * NG);      // blocks of four loads per stage
+    static constexpr int CS = ST + 4;              // column stride in floats
+    static constexpr int NB = 2 * L;               // ring slots
+    static constexpr int SLOT_FLOATS = SW * CS + ST;   // B values, then the stage's a values
+    static constexpr int LDS_BYTES = NB * SLOT_FLOATS * 4;
+};
+
+// The hand-off words live in LDS and are read and written as relaxed workgroup-scope atomics on a __shared__ object:
+// ds_read_b32 / ds_write_b32, no fence, no vector-memory wait.  (Through a pointer cast from the ring the accesses
+// came out as flat_load/flat_store with s_waitcnt vmcnt(0): every poll drained the loader's global loads.)
+__device__ __forceinline__ int hub_flag_load(const int *p)
+{
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void hub_flag_store(int *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int SW, bool WIDE>
+__global__ __launch_bounds__(64 * (1 + Hub2Cfg<SW>::L)) void spmm_hub2(HubArgs a)
+{
+    typedef Hub2Cfg<SW> K;
+    constexpr int L = K::L, U = K::U, LPS = K::LPS, NG = K::NG, NBK = K::NBK, CS = K::CS, NB = K::NB;
+    __shared__ __attribute__((aligned(16))) float ring[K::LDS_BYTES / 4];
+    __shared__ int flags[16];                                   // [w] (w < L): stages loader w has published, in its own order; [L]: stages consumed
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;
+    const int row = __builtin_amdgcn_readfirstlane(a.rows[hub].row);
+    if (row < a.row_lo || row >= a.row_hi) return;        // workgroup-uniform
+    const int beg = __builtin_amdgcn_readfirstlane(a.row_ptr[row]);
+    const int end = __builtin_amdgcn_readfirstlane(a.row_ptr[row + 1]);
+    const int len = end - beg;
+    if (len <= 0) return;
+    const int n_st = (len + K::ST - 1) / K::ST;
+    if (threadIdx.x <= L) flags[threadIdx.x] = 0;
+    __syncthreads();
+
+    if (wave == 0) {
+        // ---- the chain: lane j (mod SW) owns column j of the slice.
+        // One wave alone issues a vector instruction every ~6 cycles and a dependent v_fmac every ~5.4
+        // (scripts/experiments/fma_chain_micro.hip): the chain IS the wave's time, so nothing else may sit on it.  The
+        // 32 LDS reads of a stage cost ~12 cycles each when they are issued in front of the chain; issued one or two per
+        // four fmas, a stage AHEAD (two register sets, the loop unrolled by two so that no register is ever copied), they
+        // hide behind it: 9.4 cycles per nonzero instead of 14.8 (chain_lds_micro.hip).
+        const int cj = lane % SW;
+        const int n_full = len / K::ST;          // whole stages; a last partial one is walked element by element
+        float acc = 0.f;
+        constexpr int HQ = K::ST / 8;             // 16-byte quads per half stage
+        typedef float4v Set[HQ];
+        Set b0, a0, b1, a1;                       // set 0: first half of a stage, set 1: second half
+        // Stage t is loader t % L's stage number t / L.  The loaders run ahead (they wait for slots, not we for stages), so
+        // the count read for one stage usually covers the next ones too: it is kept in a scalar register and LDS is
+        // polled only when it runs out (a poll is a full LDS round trip on the chain: ~190 cycles per stage when done every time).
+        int seen[L];
+#pragma unroll
+        for (int w2 = 0; w2 < L; ++w2) seen[w2] = 0;
+        auto wait_ready = [&](int t) {
+            const int w2 = t % L, need = t / L + 1;
+#pragma unroll
+            for (int x = 0; x < L; ++x) {
+                if (x == w2 && seen[x] < need) {
+                    int v;
+                    while ((v = hub_flag_load(&flags[x])) < need) __builtin_amdgcn_s_sleep(1);
+                    seen[x] = v;
+                }
+            }
+            asm volatile("" ::: "memory");
+        };
+        // the chain over the half stage held in (cb, ca), with the reads of half `half` of stage tn into (nb, na) between its links
+        auto trip = [&](const Set &cb, const Set &ca, Set &nb, Set &na, int tn, int half, bool fetch) {
+            const float *bs = &ring[(tn % NB) * K::SLOT_FLOATS + cj * CS + 4 * HQ * half];
+            const float *vs = &ring[(tn % NB) * K::SLOT_FLOATS + SW * CS + 4 * HQ * half];
+            if (fetch) {
+#pragma unroll
+                for (int i = 0; i < HQ; ++i) {
+                    nb[i] = *reinterpret_cast<const float4v *>(bs + 4 * i);
+                    na[i] = *reinterpret_cast<const float4v *>(vs + 4 * i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(cb[i][e], ca[i][e], acc);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two LDS reads ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // ... then four links of the chain
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < HQ; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(cb[i][e], ca[i][e], acc);
+            }
+            asm volatile("" ::: "memory");
+        };
+        if (n_full > 0) {
+            wait_ready(0);
+            const float *bs = &ring[cj * CS], *vs = &ring[SW * CS];
+#pragma unroll
+            for (int i = 0; i < HQ; ++i) {
+                b0[i] = *reinterpret_cast<const float4v *>(bs + 4 * i);
+                a0[i] = *reinterpret_cast<const float4v *>(vs + 4 * i);
+            }
+        }
+        for (int t = 0; t < n_full; ++t) {
+            trip(b0, a0, b1, a1, t, 1, true);                 // first half of stage t; its second half arrives
+            hub_flag_store(&flags[L], t + 1);                 // stage t is in registers: its slot may be refilled
+            const bool more = t + 1 < n_full;
+            if (more) wait_ready(t + 1);
+            trip(b1, a1, b0, a0, t + 1, 0, more);             // second half; the next stage's first half arrives
+        }
+        if (n_full < n_st) {                      // the partial last stage
+            wait_ready(n_full);
+            const float *bs = &ring[(n_full % NB) * K::SLOT_FLOATS + cj * CS];
+            const float *vs = &ring[(n_full % NB) * K::SLOT_FLOATS + SW * CS];
+            for (int i = 0; i < len - K::ST * n_full; ++i) acc = __builtin_fmaf(bs[i], vs[i], acc);
+        }
+        if (lane < SW) {
+            const int col = min(slice * SW + 4 * (cj / 4), a.N - 4) + (cj & 3);
+            __builtin_nontemporal_store(acc, a.C + (int64_t)row * a.ldc + col);
+        }
+        return;
+    }
+
+    // ---- loaders: wave w takes stages w, w + L, w + 2L, ...
+    const int w = wave - 1;
+    const int part = lane % LPS, g = lane / LPS;
+    const int colf = min(slice * SW + 4 * part, a.N - 4);     // parts past N shift back (see spmm_hub)
+    const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colf * 4u;
+    struct Pairs1 { int c; float v; };
+    auto load_pairs = [&](int s) {
+        Pairs1 p;
+        const int k = min(beg + K::ST * s + lane, end - 1);   // past the row: the last pair again (valid, never consumed)
+        p.c = a.col_idx[k];
+        p.v = a.vals[k];
+        return p;
+    };
+    struct StageRegs { float4v r[NBK][4]; float v; };
+    auto issue = [&](StageRegs &R, const Pairs1 &p) {        // the stage's B-row slices: nonzero 4 NG h + 4 g + n of block h, load n
+#pragma unroll
+        for (int h = 0; h < NBK; ++h)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int c = __shfl(p.c, 4 * NG * h + 4 * g + n, 64);
+                R.r[h][n] = Vec<4>::load(b_row_ptr<WIDE>(a.B, a.ldb, ldb_bytes, col_bytes, colf, c));
+            }
+        R.v = p.v;
+    };
+    auto publish = [&](const StageRegs &R, int s) {
+        const int slot = s % NB;
+        while (hub_flag_load(&flags[L]) < s - NB + 1) __builtin_amdgcn_s_sleep(4);      // stage s - NB has been consumed
+        asm volatile("" ::: "memory");
+        float *base = &ring[slot * K::SLOT_FLOATS];
+#pragma unroll
+        for (int h = 0; h < NBK; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4v t = (float4v){R.r[h][0][e], R.r[h][1][e], R.r[h][2][e], R.r[h][3][e]};
+                *reinterpret_cast<float4v *>(base + (4 * part + e) * CS + 4 * NG * h + 4 * g) = t;
+            }
+        base[SW * CS + lane] = R.v;
+        asm volatile("" ::: "memory");
+        hub_flag_store(&flags[w], s / L + 1);     // behind the data in this wave's LDS queue
+    };
+
+    if (w >= n_st) return;
+    // Register pipeline, U stages deep.  The refills are UNCONDITIONAL and branch-free (a stage past the end re-reads the
+    // last one: valid addresses, never published): with the loads inside `if (stage exists)` hipcc's wait-count pass
+    // merged the branch states conservatively and drained the younger stages at every publish -- one stage in flight
+    // per loader instead of U.
+    // The (col, val) pairs of a stage are loaded a whole trip (U iterations) before its B rows are requested, just ahead of
+    // the B loads of the same register set: vector-memory operations retire in issue order, so by the time R[u] has
+    // landed its next pairs have too, and no wait for a pair ever drains younger B loads.
+    StageRegs R[U];
+    Pairs1 P[U];
+    const int s_last = n_st - 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) P[u] = load_pairs(min(w + u * L, s_last));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const Pairs1 p = P[u];
+        P[u] = load_pairs(min(w + (u + U) * L, s_last));
+        issue(R[u], p);
+    }
+    int s0 = w;
+    for (; s0 + (U - 1) * L < n_st; s0 += U * L) {        // all U stages of the trip exist
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u * L;
+            publish(R[u], s);
+            const Pairs1 p = P[u];                          // pairs of stage s + U L (clamped), loaded one trip ago
+            P[u] = load_pairs(min(s + 2 * U * L, s_last));
+            issue(R[u], p);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) {                       // the last, partial trip: nothing left to refill
+        const int s = s0 + u * L;
+        if (s < n_st) publish(R[u], s);
+    }
+}
+
 // ---- block path: 16-row groups with one shared column list -----------------------
 // Detection: group g = rows [16g, 16g+16) qualifies when all 16 rows have the same
 // length L >= min_len and identical column sequences.  Then

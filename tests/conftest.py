@@ -75,3 +75,29 @@ def run_spmm(device, ptr, idx, vals, B, options=None, poison=True, num_cols=None
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def expected(oracle, ptr, idx, vals, B, split=0, thr=1 << 30, chunk=256):
+    """What the product must return bit for bit: the reference's stored-order chain (spmm_ref.cu:10-14) -- the default,
+    whatever the row length -- or, with "split_long_rows" = 1, rows longer than thr summed piece by piece."""
+    if split:
+        return oracle.spmm_chunked(ptr, idx, vals, B, thr, chunk)
+    return oracle.spmm_omp(ptr, idx, vals, B)
+
+
+def auto_hub_threshold(M, N, ptr):
+    """plan.hpp resolve_hub_threshold restated: the auto rule for "long_row_threshold" in the default (exact-order) mode.
+    Largest power of two in 256 .. 8192 not above half the step's estimated time (gather-model bytes at 6 TB/s) at 200 ns per
+    nonzero, moved up while the rows above it hold more than a quarter of the nonzeros."""
+    if N < 4:
+        return (1 << 31) - 1
+    deg = np.diff(ptr).astype(np.int64)
+    nnz = int(deg.sum())
+    t = 0.5 * ((nnz * (4.0 * N + 8.0) + 4.0 * M * N) / 6e12) / 200e-9
+    cand = [256 << i for i in range(6)]
+    i = 0
+    while i + 1 < 6 and cand[i + 1] <= t:
+        i += 1
+    while i + 1 < 6 and float(deg[deg > cand[i]].sum()) > 0.25 * nnz:
+        i += 1
+    return cand[i]

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import bits, to_dev
+from conftest import auto_hub_threshold, bits, to_dev
 from hpc_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -116,9 +116,10 @@ def _run_full(device, ptr, idx, vals, d_B, N, K, options=None):
 
 
 def test_c2_power_law_full_size(device, oracle):
-    """BASELINE configs[2] at M = 2^20 (max 4096 nnz/row, N = 128): every split row and 4096 random rows against
-    the oracle evaluated in the documented piece order (bit-exact); unsplit rows bit-exact against the plain
-    oracle; the exact-order setting bit-identical to the reference's own kernel on the whole C."""
+    """BASELINE configs[2] at M = 2^20 (max 4096 nnz/row, N = 128) with DEFAULT options: the whole C bit-identical to the
+    reference's own kernel (spmm_kernel_ref compiled for this GPU) -- hub rows included, they keep their stored order
+    through the hub kernel.  The opt-in split mode: every split row and 4096 random rows against the oracle evaluated in
+    the documented piece order (bit-exact), within 1e-5 * sum|a*b| of the plain chain, plain relative error printed."""
     import torch
     from hpc_amd.spmm import count_bitdiff
 
@@ -127,33 +128,89 @@ def test_c2_power_law_full_size(device, oracle):
     assert M == 1 << 20 and 4000 <= meta["deg_max"] <= 4096      # duplicate (row, col) draws are dropped
     (d_B,) = to_dev(device, B)
     d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, M)
-    thr = op.get_option("long_row_threshold")
     deg = np.diff(ptr)
-    split = np.nonzero(deg > thr)[0]
-    assert thr == 2048 and op.get_option("n_long_rows") == split.size > 0 and op.get_option("n_medium_rows") > 0
+    # auto threshold at this size (plan.hpp resolve_hub_threshold): 4096 -- the step hides a 4096-nonzero segment on its side
+    # stream -- so every row of C2 (longest: 4095) is a short row or ONE exact segment; the hub kernel gets its full-size
+    # run below (threshold 2048)
+    assert op.get_option("long_row_threshold") == auto_hub_threshold(M, N, ptr) == 4096
+    assert op.get_option("split_long_rows") == 0 and op.get_option("n_partial_slots") == 0
+    assert op.get_option("n_hub_rows") == 0 and op.get_option("n_medium_rows") > 0
     assert not torch.isnan(d_C).any()
-    g = np.random.Generator(np.random.Philox(key=[99, 2]))
-    rows = np.unique(np.concatenate([split, [0, M - 1], g.integers(0, M, 4096)]))
-    sp, si, sv = _sample_rows(ptr, idx, vals, rows)
-    got = d_C[rows.tolist()].cpu().numpy()
-    exp = oracle.spmm_chunked(sp, si, sv, B, thr, 256)
-    assert np.array_equal(bits(got), bits(exp))
-    plain = oracle.spmm_omp(sp, si, sv, B)
-    unsplit = deg[rows] <= thr
-    assert np.array_equal(bits(got[unsplit]), bits(plain[unsplit]))
-    _, sabs = oracle.spmm_f64(sp, si, sv, B)
-    assert (np.abs(got.astype(np.float64) - plain) <= 1e-5 * sabs + 1e-30).all()      # split rows: documented tolerance
-    # exact-order setting == the reference kernel, whole matrix
+    thr = 2048
+    hubs = np.nonzero(deg > thr)[0]
     if not oracle.ref_available():
         pytest.fail("oracle/_ref missing")
     d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
     oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
-    _, _, _, d_E, ope = _run_full(device, ptr, idx, vals, d_B, N, M, {"long_row_threshold": 1 << 30})
-    assert ope.get_option("n_long_rows") == 0
-    ndiff, maxabs = count_bitdiff(d_E, d_R)
+    ndiff, maxabs = count_bitdiff(d_C, d_R)
+    assert ndiff == 0 and maxabs == 0.0, "default options must reproduce the reference kernel bit for bit on every row"
+    # ---- the 422 rows above 2048 nonzeros through the hub kernel: still the reference kernel's bits on the whole C
+    _, _, _, d_H, oph = _run_full(device, ptr, idx, vals, d_B, N, M, {"long_row_threshold": thr})
+    assert oph.get_option("n_hub_rows") == hubs.size > 0 and oph.get_option("n_partial_slots") == 0
+    ndiff, maxabs = count_bitdiff(d_H, d_R)
     assert ndiff == 0 and maxabs == 0.0
-    ndiff_auto, _ = count_bitdiff(d_C, d_R)                    # auto mode: only elements of split rows may differ
-    assert ndiff_auto <= split.size * N
+    # the hub rows once more against the CPU restatement (three-way agreement on the rows that changed path this round)
+    sp, si, sv = _sample_rows(ptr, idx, vals, hubs)
+    assert np.array_equal(bits(d_H[hubs.tolist()].cpu().numpy()), bits(oracle.spmm_omp(sp, si, sv, B)))
+    del d_H, oph
+    # ---- opt-in split mode
+    _, _, _, d_S, ops = _run_full(device, ptr, idx, vals, d_B, N, M, {"split_long_rows": 1, "long_row_threshold": thr})
+    assert ops.get_option("n_long_rows") == hubs.size and ops.get_option("n_hub_rows") == 0
+    g = np.random.Generator(np.random.Philox(key=[99, 2]))
+    rows = np.unique(np.concatenate([hubs, [0, M - 1], g.integers(0, M, 4096)]))
+    sp, si, sv = _sample_rows(ptr, idx, vals, rows)
+    got = d_S[rows.tolist()].cpu().numpy()
+    assert np.array_equal(bits(got), bits(oracle.spmm_chunked(sp, si, sv, B, thr, 256)))
+    plain = oracle.spmm_omp(sp, si, sv, B)
+    _, sabs = oracle.spmm_f64(sp, si, sv, B)
+    assert (np.abs(got.astype(np.float64) - plain) <= 1e-5 * sabs + 1e-30).all()      # split rows: documented tolerance
+    split_sel = deg[rows] > thr
+    rel = np.abs(got[split_sel].astype(np.float64) - plain[split_sel]) / np.maximum(np.abs(plain[split_sel].astype(np.float64)), 1e-300)
+    print(f"C2 split mode, {int(split_sel.sum())} split rows: plain relative error max {rel.max():.3e}, p99.9 {np.quantile(rel, 0.999):.3e}, "
+          f"share > 1e-5: {(rel > 1e-5).mean():.5f}")
+    ndiff_split, _ = count_bitdiff(d_S, d_R)                   # only elements of split rows may differ
+    assert ndiff_split <= hubs.size * N
+
+
+# name: (rows, nonzeros, longest row) -- shapes of the reference's datasets (scripts/report_table.py), N
+_HUB_GRAPHS = {
+    "rmat20": (None, None, None, 128),
+    "ddi": (4_267, 2_135_822, 2_234, 128),
+    "reddit": (232_965, 114_615_892, 21_657, 32),
+    "am": (881_680, 5_668_682, 154_828, 128),
+}
+
+
+@pytest.mark.parametrize("name", list(_HUB_GRAPHS))
+def test_hub_graphs_default_options_bit_identical_to_reference_kernel(device, oracle, name):
+    """Graphs whose longest rows are far beyond the split threshold (R-MAT scale 20: a 64 K-nonzero hub; ddi-, reddit- and
+    am-shaped: 2 K ... 155 K), default options: count_bitdiff(ours, spmm_kernel_ref) == 0 over the whole C."""
+    import torch
+    from hpc_amd.spmm import count_bitdiff
+
+    rows, nnz_t, mx, N = _HUB_GRAPHS[name]
+    if name == "rmat20":
+        ptr, idx = synth.csr_rmat(20, 32)
+    else:
+        ptr, idx = synth.csr_powerlaw(rows, nnz_t / rows, min(mx, rows), seed=sum(map(ord, name)) % 1000 + 1, force_max=True)
+    M = ptr.size - 1
+    vals = synth.make_values(idx.size)
+    d_B = torch.empty(M * N, dtype=torch.float32, device=device)
+    from hpc_amd.spmm import fill_normal
+    fill_normal(d_B, 125, 0, 0.0, 0.1)
+    d_B = d_B.view(M, N)
+    d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, M)
+    deg = np.diff(ptr)
+    thr = op.get_option("long_row_threshold")
+    assert thr == auto_hub_threshold(M, N, ptr)
+    assert op.get_option("n_hub_rows") == int((deg > thr).sum()) and op.get_option("n_partial_slots") == 0
+    assert op.get_option("n_hub_rows") > 0 or name == "ddi"     # ddi-shaped: the auto threshold sits near its longest row
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    ndiff, maxabs = count_bitdiff(d_C, d_R)
+    assert ndiff == 0 and maxabs == 0.0, (name, int(deg.max()), thr, ndiff)
 
 
 def test_c4_block_dense_full_size(device, oracle):

@@ -1,15 +1,16 @@
 """Parity tests proper: the HIP path, called through the C ABI, against the oracle.
 
-Bar (BASELINE.json north_star): bit-exact wherever the summation order is the reference's
-(every row at or below the split threshold); rows split into chunks are bit-exact against the
-oracle evaluated in the same chunk order and within 1e-5 * sum|a_k b_k| of the plain oracle."""
+Bar (BASELINE.json north_star): bit-exact against the reference's stored-order fma chain on EVERY row with default
+options (short rows, medium segments, hub rows through the hub kernel, block groups through the f32 MFMA).  Only the
+opt-in "split_long_rows" = 1 changes a summation order: those rows are bit-exact against the oracle evaluated in the
+same piece order and within 1e-5 * sum|a_k b_k| of the plain oracle."""
 import glob
 import os
 
 import numpy as np
 import pytest
 
-from conftest import bits, run_spmm, to_dev
+from conftest import auto_hub_threshold, expected, bits, run_spmm, to_dev
 from hpc_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -52,18 +53,19 @@ def test_bitwise_over_tuning_knobs(device, oracle, block_threads, pol, N):
         assert np.array_equal(bits(C), bits(ref)), (rpb, xcd)
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("N", [64, 128, 256, 300, 1024])
-def test_bitwise_over_column_tile_widths(device, oracle, N):
+def test_bitwise_over_column_tile_widths(device, oracle, N, split):
     """"tile_cols" (widest column tile of the rows / segment kernels; auto picks 64 for wide B with random columns and
     whole-wave tiles for banded structure) is scheduling only: every width gives the oracle's bits -- short rows, medium
-    rows (one exact segment), split rows (documented piece order)."""
+    rows (one exact segment), hub rows (stored order through the hub kernel; with "split_long_rows" the documented piece order)."""
     ptr, idx = synth.csr_powerlaw(3000, 30.0, 1200, K=20000, seed=77)
     vals = synth.normal_f32(idx.size, 78)
     B = synth.normal_f32(20000 * N, 79).reshape(20000, N)
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, 300, 64)
+    exp = expected(oracle, ptr, idx, vals, B, split, 300, 64)
     seen = set()
     for tile in (0, 32, 64, 128, 256):
-        C, op = run_spmm(device, ptr, idx, vals, B, options={"tile_cols": tile, "long_row_threshold": 300, "long_row_chunk": 64})
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"tile_cols": tile, "long_row_threshold": 300, "long_row_chunk": 64, "split_long_rows": split})
         assert np.array_equal(bits(C), bits(exp)), tile
         seen.add(op.get_option("lanes_per_row"))
     assert len(seen) >= (2 if N == 64 else 3)
@@ -97,18 +99,20 @@ def test_empty_matrix_and_zero_width(device):
     torch.cuda.synchronize()
 
 
-def test_overwrite_and_idempotent(device, oracle):
+@pytest.mark.parametrize("split", [0, 1])
+def test_overwrite_and_idempotent(device, oracle, split):
     """run() leaves vout = A*vin whatever vout held (spmm_ref.cu:15, cuSPARSE beta=0) and may be
     called back to back (util.h:143-149) -- unlike the student kernel, which accumulates (H7)."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
-    ptr, idx, vals, B = _rand_case(3000, 3000, 64, 0, 600, seed=9)   # includes split rows (> 512)
+    ptr, idx, vals, B = _rand_case(3000, 3000, 64, 0, 600, seed=9)   # includes hub rows (> 512)
     assert ptr[-1] == idx.size
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((3000, 64), 1e30, dtype=torch.float32, device=device)
     op = SpMMOpt(CSR(3000, idx.size, d_ptr, d_idx, d_val), 64)
     op.set_option("long_row_threshold", 512)
+    op.set_option("split_long_rows", split)
     op.preprocess(d_B, d_C)
     assert op.get_option("n_long_rows") > 0 and op.get_option("n_medium_rows") > 0
     op.run(d_B, d_C)
@@ -117,15 +121,19 @@ def test_overwrite_and_idempotent(device, oracle):
         op.run(d_B, d_C)
     torch.cuda.synchronize()
     assert torch.equal(first.view(torch.int32), d_C.view(torch.int32))
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+    exp = expected(oracle, ptr, idx, vals, B, split, 512, 256)
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
 
 
 @pytest.mark.parametrize("thr,chunk", [(8, 8), (16, 5), (64, 64), (100, 256)])
 @pytest.mark.parametrize("N", [5, 32, 128, 256])
 def test_split_rows_chunk_order_and_tolerance(device, oracle, thr, chunk, N):
+    """The OPT-IN order-changing path ("split_long_rows" = 1): rows longer than the threshold are summed piece by piece in
+    piece order -- bit-exact against the oracle evaluated in that order, within 1e-5 * sum|a*b| of the plain chain; the
+    plain relative error north_star names is printed as statistics (it is unbounded near cancellation).
+    The DEFAULT path on the same input keeps every row in stored order: bit-identical to the plain oracle."""
     ptr, idx, vals, B = _rand_case(400, 900, N, 0, 300, seed=31)
-    C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": thr, "long_row_chunk": chunk})
+    C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": thr, "long_row_chunk": chunk, "split_long_rows": 1})
     assert op.get_option("n_long_rows") == int((np.diff(ptr) > thr).sum())
     exp = oracle.spmm_chunked(ptr, idx, vals, B, thr, chunk)
     assert np.array_equal(bits(C), bits(exp)), "device chunk order differs from the documented one"
@@ -134,20 +142,34 @@ def test_split_rows_chunk_order_and_tolerance(device, oracle, thr, chunk, N):
     assert (np.abs(C.astype(np.float64) - plain) <= TOL_SPLIT * sabs + 1e-30).all()
     short = np.diff(ptr) <= thr
     assert np.array_equal(bits(C[short]), bits(plain[short])), "rows below the threshold must stay bit-exact"
+    rel = np.abs(C[~short].astype(np.float64) - plain[~short]) / np.maximum(np.abs(plain[~short].astype(np.float64)), 1e-300)
+    if rel.size:
+        print(f"split rows thr={thr} chunk={chunk} N={N}: plain relative error max {rel.max():.3e}, p99.9 {np.quantile(rel, 0.999):.3e}, "
+              f"share > 1e-5: {(rel > 1e-5).mean():.4f}")
+    C0, op0 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": thr, "long_row_chunk": chunk})
+    assert op0.get_option("split_long_rows") == 0 and op0.get_option("n_partial_slots") == 0
+    assert op0.get_option("n_hub_rows") == (int((np.diff(ptr) > thr).sum()) if N >= 4 else 0)
+    assert np.array_equal(bits(C0), bits(plain)), "the default path must keep the stored order on every row"
 
 
 def test_power_law_rows(device, oracle):
     ptr, idx = synth.csr_powerlaw(20000, 32.0, 4096, seed=5)
     vals = synth.normal_f32(idx.size, 6)
     B = synth.normal_f32(20000 * 128, 7).reshape(20000, 128)
+    plain = oracle.spmm_omp(ptr, idx, vals, B)
     C, op = run_spmm(device, ptr, idx, vals, B)
-    thr = op.get_option("long_row_threshold")          # auto: clamp(nnz / 8192, 256, 2048)
-    assert thr == min(2048, max(256, idx.size // 8192)) and op.get_option("n_long_rows") > 0
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, thr, 256)
-    assert np.array_equal(bits(C), bits(exp))
-    C5, op5 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 100, "long_row_chunk": 70})
+    thr = op.get_option("long_row_threshold")          # auto (exact mode): plan.hpp resolve_hub_threshold
+    assert thr == auto_hub_threshold(20000, 128, ptr) < 4000 and op.get_option("n_hub_rows") == op.get_option("n_long_rows") > 0
+    assert np.array_equal(bits(C), bits(plain)), "default options: hubs through the hub kernel, stored order"
+    Cs, ops = run_spmm(device, ptr, idx, vals, B, options={"split_long_rows": 1})
+    thr_s = ops.get_option("long_row_threshold")       # auto (split mode): clamp(nnz / 8192, 256, 2048)
+    assert thr_s == min(2048, max(256, idx.size // 8192))
+    assert np.array_equal(bits(Cs), bits(oracle.spmm_chunked(ptr, idx, vals, B, thr_s, 256)))
+    C5, op5 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 100, "long_row_chunk": 70, "split_long_rows": 1})
     assert op5.get_option("n_long_rows") > op.get_option("n_long_rows")
     assert np.array_equal(bits(C5), bits(oracle.spmm_chunked(ptr, idx, vals, B, 100, 70)))
+    C6, op6 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 100})
+    assert op6.get_option("n_hub_rows") == op5.get_option("n_long_rows") and np.array_equal(bits(C6), bits(plain))
     C2, _ = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 1 << 30})
     assert np.array_equal(bits(C2), bits(oracle.spmm_omp(ptr, idx, vals, B)))
 
@@ -519,10 +541,11 @@ def test_block_items_row_panels_pitches_and_special_values(device, oracle):
     assert np.isnan(got[:37]).all() and np.isnan(got[999:]).all()
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("N", [32, 128, 36])
-def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N):
+def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N, split):
     """mi_spmm_run_rows on an arbitrary range: exactly those rows of C are written -- short rows, medium rows
-    (segment kernel), split rows (pieces + ordered reduce) and rows of block groups cut by the range boundary."""
+    (segment kernel), hub rows (hub kernel; or pieces + ordered reduce) and rows of block groups cut by the range boundary."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
@@ -538,6 +561,8 @@ def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=2500)
     op.set_option("long_row_threshold", 256)
+    op.set_option("split_long_rows", split)
+    op.set_option("hub_overlap", 2)
     full = torch.empty(M, N, dtype=torch.float32, device=device)
     op.preprocess(d_B, full)
     assert op.get_option("n_long_rows") >= 3 and op.get_option("n_medium_rows") >= 2
@@ -547,7 +572,7 @@ def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N
     ref_full = full.cpu().numpy()
     # split rows carry the documented tolerance against the oracle; everything else is bit-exact
     exp = oracle.spmm_omp(ptr, idx, vals, B)
-    unsplit = np.diff(ptr) <= 256
+    unsplit = (np.diff(ptr) <= 256) if split else np.ones(M, bool)
     assert np.array_equal(bits(ref_full)[unsplit], bits(exp)[unsplit])
     for r0, r1 in ((0, M), (5, 6), (7, 41), (100, 333), (M - 9, M), (M - 7, M - 2), (17, 17)):
         C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
@@ -584,7 +609,7 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     try:
         M, n_loc = 5000, 128
-        ptr, idx = synth.csr_powerlaw(M, 24.0, 2000, seed=8)       # includes split rows
+        ptr, idx = synth.csr_powerlaw(M, 24.0, 2000, seed=8)       # includes hub rows
         vals = synth.normal_f32(idx.size, 9)
         B = synth.normal_f32(M * n_loc, 10).reshape(M, n_loc)
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
@@ -597,7 +622,8 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
         for _ in range(3):
             sh.run(d_B, C_loc, C_full)
         torch.cuda.synchronize()
-        exp = oracle.spmm_chunked(ptr, idx, vals, B, op.get_option("long_row_threshold"), op.get_option("long_row_chunk"))
+        assert op.get_option("n_hub_rows") > 0
+        exp = oracle.spmm_omp(ptr, idx, vals, B)
         assert np.array_equal(bits(C_full.cpu().numpy()), bits(exp))
     finally:
         if created:
@@ -634,7 +660,7 @@ def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
     for _ in range(3):
         sh.run(d_B, d_C)
     torch.cuda.synchronize()
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, 256, 256)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
     assert (sh.get_option("staging_bytes") > 0) == (exchange != "peer2d")
     # the two legs on their own (bench.py's breakdown: timing legs; with staging the panels share two buffers, so only
@@ -750,21 +776,25 @@ def test_native_harness_end_to_end(device, tmp_path):
         assert os.path.exists(tmp_path / "syn.graph.ptrdump") and os.path.exists(tmp_path / "syn.graph.edgedump")
 
 
-def test_run_is_graph_capturable_and_stream_ordered(device, oracle):
+@pytest.mark.parametrize("overlap", [0, 2])
+@pytest.mark.parametrize("split", [0, 1])
+def test_run_is_graph_capturable_and_stream_ordered(device, oracle, split, overlap):
     """run() allocates nothing and never synchronises: it can be captured into a HIP
     graph and replayed, and it runs on the caller's stream (the reference: null stream, util.h:133-136)."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
-    ptr, idx = synth.csr_powerlaw(6000, 24.0, 2000, seed=3)      # rows + chunks + reduce: three launches
+    ptr, idx = synth.csr_powerlaw(6000, 24.0, 2000, seed=3)      # hub + segments + rows (split: segments + rows + reduce): three launches
     vals = synth.normal_f32(idx.size, 4)
     B = synth.normal_f32(6000 * 64, 5).reshape(6000, 64)
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((6000, 64), float("nan"), device=device)
     op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
     op.set_option("long_row_threshold", 512)
+    op.set_option("split_long_rows", split)
+    op.set_option("hub_overlap", overlap)      # 2: hub and segment kernels on the handle's side streams, forked and joined inside run()
     op.preprocess(d_B, d_C)
-    exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
+    exp = expected(oracle, ptr, idx, vals, B, split, 512, 256)
     side = torch.cuda.Stream(device=device)
     with torch.cuda.stream(side):
         op.run(d_B, d_C)
@@ -787,25 +817,28 @@ def test_run_is_graph_capturable_and_stream_ordered(device, oracle):
 
 
 def test_rmat_and_banded_structures(device, oracle):
-    """Hub-dominated (R-MAT) and locality-rich (banded) graphs: hubs go through the split path, everything
-    else stays bit-exact."""
+    """Hub-dominated (R-MAT) and locality-rich (banded) graphs: every row bit-exact by default (hubs through the hub
+    kernel); with "split_long_rows" the hubs follow the documented piece order."""
     for name, (ptr, idx) in {"rmat": synth.csr_rmat(14, 16, seed=2), "banded": synth.csr_banded(20000, 4, 40, width=300, seed=2)}.items():
         M = ptr.size - 1
         vals = synth.normal_f32(idx.size, 3)
         B = synth.normal_f32(M * 64, 4).reshape(M, 64)
-        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512})
+        plain = oracle.spmm_omp(ptr, idx, vals, B)
+        C0, op0 = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512})
+        assert np.array_equal(bits(C0), bits(plain)), name
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512, "split_long_rows": 1})
         exp = oracle.spmm_chunked(ptr, idx, vals, B, 512, 256)
         assert np.array_equal(bits(C), bits(exp)), name
         if name == "rmat":
-            assert op.get_option("n_long_rows") > 0 and (np.diff(ptr) == 0).any()
-            plain = oracle.spmm_omp(ptr, idx, vals, B)
+            assert op.get_option("n_long_rows") > 0 and op0.get_option("n_hub_rows") > 0 and (np.diff(ptr) == 0).any()
             _, sabs = oracle.spmm_f64(ptr, idx, vals, B)
             assert (np.abs(C.astype(np.float64) - plain) <= TOL_SPLIT * sabs + 1e-30).all()
 
 
 def test_fuzz_shapes_pitches_thresholds(device, oracle):
     """80 seeded random cases: ragged shapes, K != M, odd widths, row pitches wider than N, both rows
-    kernels, random medium/split thresholds -- always bit-equal to the oracle in the documented order."""
+    kernels, random medium / hub thresholds, hubs in stored order (default) or split -- always bit-equal to the oracle in the
+    documented order."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
@@ -826,7 +859,8 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
         Bp = synth.normal_f32(K * ldb, 9000 + case).reshape(K, ldb)
         opts = {"medium_row_threshold": int(g.choice([0, 1, 5, 64, 1000])),
                 "long_row_threshold": int(g.choice([6, 40, 2048])), "long_row_chunk": int(g.choice([3, 16, 256])),
-                "block_path": int(g.choice([0, 1])), "segment_unroll": int(g.choice([8, 16, 32]))}
+                "block_path": int(g.choice([0, 1])), "segment_unroll": int(g.choice([8, 16, 32])), "split_long_rows": int(case % 3 == 2),
+                "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3]}
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
         d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
@@ -841,7 +875,7 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
             op.run_ld(d_B, ldb, d_C, ldc)
         torch.cuda.synchronize()
         got = d_C.cpu().numpy()
-        exp = oracle.spmm_chunked(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["long_row_threshold"], opts["long_row_chunk"])
+        exp = expected(oracle, ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["split_long_rows"], opts["long_row_threshold"], opts["long_row_chunk"])
         assert np.array_equal(bits(got[:, :N]), bits(exp)), (case, M, K, N, ldb, ldc, opts)
         assert np.isnan(got[:, N:]).all(), "wrote outside its N columns"
 
@@ -900,7 +934,7 @@ def test_fuzz_block_items(device, oracle):
         ldb = N + int(g.choice([0, 0, 4, 64]))
         ldc = N + int(g.choice([0, 0, 4, 128]))
         Bp = synth.normal_f32(K * ldb, 8000 + case).reshape(K, ldb)
-        opts = {"long_row_threshold": int(g.choice([256, 2048])), "block_share": int(g.choice([1, 2])), "block_max_pieces": int(g.choice([1, 2, 4])),
+        opts = {"split_long_rows": case % 2, "long_row_threshold": int(g.choice([256, 2048])), "block_share": int(g.choice([1, 2])), "block_max_pieces": int(g.choice([1, 2, 4])),
                 "block_run_min": int(g.choice([8, 32, 64])), "block_min_len": int(g.choice([8, 30]))}
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
         d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
@@ -917,7 +951,7 @@ def test_fuzz_block_items(device, oracle):
             op.run_ld(d_B, ldb, d_C, ldc)              # a second step over the carried tiles of the first
         torch.cuda.synchronize()
         got = d_C.cpu().numpy()
-        exp = oracle.spmm_chunked(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["long_row_threshold"], 256)
+        exp = expected(oracle, ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]), opts["split_long_rows"], opts["long_row_threshold"], 256)
         assert np.array_equal(bits(got[:, :N]), bits(exp)), (case, M, K, N, ldb, ldc, opts, op.get_option("n_block_groups"), op.get_option("n_block_passes"))
         assert np.isnan(got[:, N:]).all(), "wrote outside its N columns"
         seen["groups"] += op.get_option("n_block_groups")
@@ -927,7 +961,7 @@ def test_fuzz_block_items(device, oracle):
 
 
 def test_special_values_all_paths(device, oracle):
-    """inf, NaN, -0.0 and subnormals in A and B through the rows, segment (medium + split) and MFMA block
+    """inf, NaN, -0.0 and subnormals in A and B through the rows, segment (medium), hub (and split) and MFMA block
     paths: same bits as the oracle (NaNs compared as NaN: payloads are not part of the contract).
     Guards the kernels' padding trick (empty slots are fma(+0, +0, acc)) and the f32 MFMA's subnormal handling."""
     g = np.random.Generator(np.random.Philox(key=[77, 7]))
@@ -941,8 +975,8 @@ def test_special_values_all_paths(device, oracle):
     special = np.array([np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-40, -3e-42, 1.1754942e-38, 3.4e38, -3.4e38], np.float32)
     vals[g.integers(0, vals.size, 400)] = special[g.integers(0, special.size, 400)]
     B.reshape(-1)[g.integers(0, B.size, 4000)] = special[g.integers(0, special.size, 4000)]
-    ref = oracle.spmm_chunked(ptr, idx, vals, B, 256, 64)
-    for opts in ({}, {"block_path": 0}, {"rows_per_block": 1000}):
+    for opts in ({}, {"block_path": 0}, {"rows_per_block": 1000}, {"split_long_rows": 1}, {"hub_slice": 16}, {"hub_slice": 64}):
+        ref = expected(oracle, ptr, idx, vals, B, opts.get("split_long_rows", 0), 256, 64)
         o = {"long_row_threshold": 256, "long_row_chunk": 64}
         o.update(opts)
         C, op = run_spmm(device, ptr, idx, vals, B, options=o)
@@ -969,17 +1003,17 @@ def test_gpu_and_host_plan_builders_agree(device, oracle):
         K = max(M, int(idx.max()) + 1 if idx.size else 1)
         vals = synth.normal_f32(idx.size, 8)
         B = synth.normal_f32(K * 128, 9).reshape(K, 128)
-        for thr in (0, 100):                                   # auto and a low explicit threshold
+        for thr, split in ((0, 0), (100, 0), (0, 1), (100, 1)):    # auto and a low explicit threshold; hubs whole or in pieces
             res = {}
             for gpu_pre in (1, 0):
                 C, op = run_spmm(device, ptr, idx, vals, B, options={"gpu_preprocess": gpu_pre, "long_row_threshold": thr,
-                                                                    "long_row_chunk": 64})
-                res[gpu_pre] = (C, {k: op.get_option(k) for k in ("n_chunks", "n_long_rows", "n_medium_rows", "n_partial_slots",
+                                                                    "long_row_chunk": 64, "split_long_rows": split})
+                res[gpu_pre] = (C, {k: op.get_option(k) for k in ("n_chunks", "n_long_rows", "n_hub_rows", "n_medium_rows", "n_partial_slots",
                                                                   "n_block_groups", "max_row_nnz", "long_row_threshold")})
-            assert res[1][1] == res[0][1], (name, thr, res[1][1], res[0][1])
-            assert np.array_equal(bits(res[1][0]), bits(res[0][0])), (name, thr)
+            assert res[1][1] == res[0][1], (name, thr, split, res[1][1], res[0][1])
+            assert np.array_equal(bits(res[1][0]), bits(res[0][0])), (name, thr, split)
             t = res[1][1]["long_row_threshold"]
-            assert np.array_equal(bits(res[1][0]), bits(oracle.spmm_chunked(ptr, idx, vals, B, t, 64))), (name, thr)
+            assert np.array_equal(bits(res[1][0]), bits(expected(oracle, ptr, idx, vals, B, split, t, 64))), (name, thr, split)
 
 
 def test_unaligned_pointers_fall_back_cleanly(device, oracle):
@@ -1019,7 +1053,7 @@ def test_wide_addressing_variants(device, oracle):
     K, N, ldb = 96, 128, (1 << 22) + 8
     ptr, idx, vals, Bs, kinds = _shared_list_case(20, K, N, seed=808)              # block groups + ragged rows
     g = np.random.Generator(np.random.Philox(key=[8, 8]))
-    extra = [g.integers(0, K, size=d).astype(np.int32) for d in (700, 150)]          # a split row and a medium row
+    extra = [g.integers(0, K, size=d).astype(np.int32) for d in (700, 150)]          # a hub row and a medium row
     idx = np.concatenate([idx] + extra)
     ptr = np.concatenate([ptr, ptr[-1] + np.cumsum([e.size for e in extra])]).astype(np.int32)
     vals = synth.normal_f32(idx.size, 2)
@@ -1035,7 +1069,8 @@ def test_wide_addressing_variants(device, oracle):
     op.run_ld(d_B, ldb, d_C, N)
     torch.cuda.synchronize()
     assert op.get_option("wide_addressing") == 1 and op.get_option("vector_width") == 4
-    exp = oracle.spmm_chunked(ptr, idx, vals, Bs, 256, 256)
+    exp = oracle.spmm_omp(ptr, idx, vals, Bs)
+    assert op.get_option("n_hub_rows") == 1
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
     for rpb in (0, 1000):                     # long lane-group runs through the wide variants too
         op.set_option("rows_per_block", rpb)
