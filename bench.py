@@ -24,6 +24,10 @@ roofline: C1/C2/...: dominant kernel = spmm_rows_v2; achieved = algorithmic byte
           include Infinity-Cache hits, so it can exceed what HBM alone delivers (6.29 TB/s copy).
           C4 (block-dense): dominant kernel = spmm_block_items on the f32 MFMA; bound "mfma",
           achieved = 2*nnz*N / step, peak 157.3 TFLOP/s, with the byte models beside it.
+also:     N = 1 and the default configuration only: the other single-GPU BASELINE configurations -- C2 (power-law rows),
+          C4 (block-dense rows, N = 256, MFMA path) and C1's CSR at N = 1024 (configs[3]'s one-GPU leg) -- each timed with
+          the same HIP-event protocol AFTER the headline's timed region (so the driver's clock brackets them too); inputs
+          regenerated from the seeds (structure) and filled on the device (values, B).  {config, ms_per_step, value, roofline}.
 cpu_baseline: the oracle's OpenMP restatement ("port") timed on this box's host cores on the same
           workload (rank 0, N = 1 only), all cores and one thread.  Baseline and checker only.
 """
@@ -59,6 +63,7 @@ def parse():
                          "three before the warm-up and keep the fastest (ranks agree collectively)")
     ap.add_argument("--opt", action="append", default=[], help="key=value handle option (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N=1, C1: skip the `also` object (C2, C4 and C1 at N=1024, timed after the headline)")
     ap.add_argument("--no-strong-reference", action="store_true", help="N>1: skip the one-GPU-all-columns reference timing")
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the workload the CPU baseline runs (default: all for C1)")
     ap.add_argument("--check", action="store_true", help="verify a row sample against the oracle after timing")
@@ -317,6 +322,10 @@ def main():
             ts.append(time.perf_counter() - t)
         ref_protocol_ms = float(np.mean(ts)) * 1e3
 
+    also = None
+    if not multi and rank == 0 and name == "C1" and not args.no_also and not args.opt:
+        also = also_configs(args, dev, (d_ptr, d_idx, nnz), M)
+
     check = None
     if args.check:
         from oracle import oracle
@@ -452,7 +461,9 @@ def main():
                     "block_items": {k: op.get_option(k) for k in ("n_block_groups", "n_block_pieces", "n_block_items", "n_block_shared_items",
                                                                   "n_block_passes")}}
         elif achieved is not None:
-            roof = {"bound": "hbm", "kernel": "mi::spmm_rows_v2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "bound_detail": "l2_fabric (gather model): algorithmic bytes over the L2<->fabric path, Infinity-Cache hits "
+                    "included; the contract's token stays \"hbm\", the HBM copy ceiling is frac_of_measured_copy_6290's denominator",
+                    "kernel": "mi::spmm_rows_v2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "rate_kind": "algorithmic (gather model) bytes / step time; the L2<->fabric path incl. Infinity-Cache hits carries it, "
                                  "so it may exceed the 6.29 TB/s HBM copy rate",
@@ -483,6 +494,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if also is not None:
+            line["also"] = also
         if multi:
             line["strong_reference_ms"] = round(strong_ref, 4) if strong_ref else None
             line["strong_reference_note"] = (f"one GPU, all N={n_total} columns, same CSR (rank 0, outside the timed region); "
@@ -497,6 +510,98 @@ def main():
     if multi:
         del sharded
         dist.destroy_process_group()
+
+
+def also_configs(args, dev, c1_tensors, M):
+    """C2, C4 and C1-at-N=1024 on this GPU, one after the other, each: preprocess (untimed), 3 warm-up runs, args.steps
+    timed runs with a HIP event pair per run on the launch stream.  Values and B are N(0, 0.1) filled on the device
+    (mi_spmm_fill_normal); structures come from the same seeded generators as the tests' configurations."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt, synth
+    from hpc_amd.spmm import fill_normal
+
+    traffic_file = {}
+    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tp):
+        try:
+            traffic_file = json.load(open(tp))
+        except Exception:
+            traffic_file = {}
+
+    def run_one(tag, d_ptr, d_idx, n, nnz, extra):
+        d_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+        fill_normal(d_val, synth.SEED_VALS)
+        d_B = torch.empty(M * n, dtype=torch.float32, device=dev)
+        fill_normal(d_B, synth.SEED_B)
+        d_B = d_B.view(M, n)
+        d_C = torch.empty((M, n), dtype=torch.float32, device=dev)
+        op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), n)
+        op.preprocess(d_B, d_C)
+        torch.cuda.synchronize()
+        t = time.time()
+        op.preprocess(d_B, d_C)
+        torch.cuda.synchronize()
+        pre_ms = (time.time() - t) * 1e3
+        for _ in range(3):
+            op.run(d_B, d_C)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(1, args.steps))]
+        torch.cuda.synchronize()
+        for a, b in ev:
+            a.record()
+            op.run(d_B, d_C)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        model = synth.bytes_model(M, M, n, nnz)
+        flops = 2.0 * nnz * n
+        tj = traffic_file.get(tag)
+        traffic = tj.get("hbm_bytes_per_launch") if tj and tj.get("N") == n and M == (1 << 20) else None
+        src = ({"file": tj.get("source"), "commit": tj.get("commit"), "note": "rocprofv3 --pmc passes at that commit, not this run"}
+               if traffic is not None else None)
+        n_blk = op.get_option("n_block_groups")
+        if n_blk * 16 * 2 > M:
+            tf = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "bound_detail": "fp32 MFMA (v_mfma_f32_16x16x4_f32) peak 157.3 TFLOP/s; the step is also reported on its bytes",
+                    "kernel": "mi::spmm_block_items", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                    "bytes_min": model["bytes_min"], "GBs_on_bytes_min": round(model["bytes_min"] / (ms * 1e-3) / 1e9, 1),
+                    "traffic": traffic, "traffic_source": src, "launches_per_step": op.get_option("n_launches"),
+                    "block_items": {k: op.get_option(k) for k in ("n_block_groups", "n_block_pieces", "n_block_items",
+                                                                  "n_block_shared_items", "n_block_passes")}}
+        else:
+            gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "bound_detail": "l2_fabric (gather model): algorithmic bytes over the L2<->fabric path, Infinity-Cache hits included",
+                    "kernel": "mi::spmm_rows_v2 (+ segment / hub kernels on their side streams)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(gbs / 6290.0, 4),
+                    "bytes_alg": model["bytes_alg"], "bytes_min": model["bytes_min"], "traffic": traffic, "traffic_source": src,
+                    "launches_per_step": op.get_option("n_launches")}
+        out = {"config": f"{tag}: {extra}, M=K={M}, nnz={nnz}, N={n} fp32", "ms_per_step": round(ms, 4), "steps": len(ev),
+               "value": round(flops / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "preprocess_ms": round(pre_ms, 2), "roofline": roof,
+               "summation_order": ("exact (stored order on every row)" if not op.get_option("split_long_rows") else "split"),
+               "options": {k: op.get_option(k) for k in ("long_row_threshold", "n_hub_rows", "n_medium_rows", "lanes_per_row", "tile_cols")}}
+        del op, d_val, d_B, d_C
+        torch.cuda.empty_cache()
+        return out
+
+    res = {}
+    try:
+        ptr, idx = synth.csr_powerlaw(M, 32.0, 4096)
+        d_ptr, d_idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+        res["C2"] = run_one("C2", d_ptr, d_idx, 128, int(idx.size), f"power-law rows (max {int(np.diff(ptr).max())})")
+        del d_ptr, d_idx, ptr, idx
+    except Exception as e:
+        res["C2"] = {"error": repr(e)[:200]}
+    try:
+        d_ptr, d_idx = synth.csr_block_dense_fast_device(M, dev)
+        res["C4"] = run_one("C4", d_ptr, d_idx, 256, int(d_idx.numel()), "block-dense rows (16-row groups sharing 1-2 runs of 64-128 columns)")
+        del d_ptr, d_idx
+    except Exception as e:
+        res["C4"] = {"error": repr(e)[:200]}
+    try:
+        d_ptr, d_idx, nnz = c1_tensors
+        res["C1_N1024"] = run_one("C1_N1024", d_ptr, d_idx, 1024, nnz, "C1's CSR, the one-GPU leg of configs[3]")
+    except Exception as e:
+        res["C1_N1024"] = {"error": repr(e)[:200]}
+    return res
 
 
 def cpu_baseline(args, ptr, idx, vals, B, M, N):
@@ -538,6 +643,8 @@ def cpu_baseline(args, ptr, idx, vals, B, M, N):
         "sample": f"rows [0,{rows}) of the same workload ({nnz} nnz, N={N}), mean of {reps} runs after 1 warm-up, "
                   f"{best * 1e3:.1f} ms each; oracle/spmm_oracle.c oracle_spmm_omp, {flags}",
         "seconds": round(best, 4), "host_cpus": os.cpu_count(),
+        "cores_note": f"{threads} OpenMP threads = the CPUs this job may run on (its cgroup / affinity share of the host's "
+                      f"{os.cpu_count()}): BASELINE.md's 'all physical cores' means all cores the job is given",
         "single_thread": {"value": round(2.0 * nnz1 * N / best1 / 1e9, 3), "unit": "GFLOP/s", "cores": 1,
                           "sample": f"rows [0,{rows1}) ({nnz1} nnz), mean of {reps1} runs after 1 warm-up, {best1 * 1e3:.1f} ms each"},
     }

@@ -38,7 +38,6 @@ struct mi_spmm_handle {
     int64_t medium_res;  // the value in force after preprocess (auto resolved, capped by long_thr)
     int64_t split_long;   // 0 (default): hubs keep their stored order (spmm_hub); 1: hubs are cut into pieces summed piece by piece
     int64_t hub_slice;    // columns per hub wave: 16, 32, 64; 0 = auto
-    int64_t hub_kernel;   // 2 (default): loader waves + chain wave (spmm_hub2); 1: one wave per slice fed by LDS-DMA (spmm_hub)
     int64_t hub_overlap;  // 1 (default): the hub kernel and the segment kernel run on handle-owned side streams, forked from and joined
                           // back into the caller's stream inside every run call (their longest rows then overlap the rows kernel)
     hipStream_t side[2];  // [0]: hub kernel, [1]: segment (+ reduce) kernels; created by the first preprocess that needs them
@@ -418,7 +417,6 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->split_long = 0;     // every row one chain in stored order (the reference's definition, spmm_ref.cu:10-14)
     h->hub_slice = 0;
     h->hub_overlap = 1;
-    h->hub_kernel = 2;
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
     h->xcd_remap = -1;     // auto (see run)
@@ -475,7 +473,6 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
     else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
     else if (k == "hub_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->hub_overlap = v; free_plan(h); }
-    else if (k == "hub_kernel") { if (v != 1 && v != 2) return MI_SPMM_EINVAL; h->hub_kernel = v; }
     else if (k == "long_row_chunk") { if (v < 1 || v > kMaxLongChunk) return MI_SPMM_EINVAL; h->long_chunk = v; free_plan(h); }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
@@ -512,7 +509,6 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "split_long_rows") *value = h->split_long;
     else if (k == "hub_slice") *value = h->hub_slice;
     else if (k == "hub_overlap") *value = h->hub_overlap;
-    else if (k == "hub_kernel") *value = h->hub_kernel;
     else if (k == "n_hub_rows") *value = h->split_long ? 0 : h->n_long;
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
@@ -859,19 +855,11 @@ void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 g
 }
 
 template <bool WIDE>
-void launch_hub2(int sw, const HubArgs &a, dim3 grid, hipStream_t s)
-{
-    if (sw == 16) hipLaunchKernelGGL((spmm_hub2<16, WIDE>), grid, dim3(64 * (1 + Hub2Cfg<16>::L)), 0, s, a);
-    else if (sw == 64) hipLaunchKernelGGL((spmm_hub2<64, WIDE>), grid, dim3(64 * (1 + Hub2Cfg<64>::L)), 0, s, a);
-    else hipLaunchKernelGGL((spmm_hub2<32, WIDE>), grid, dim3(64 * (1 + Hub2Cfg<32>::L)), 0, s, a);
-}
-
-template <bool WIDE>
 void launch_hub(int sw, const HubArgs &a, dim3 grid, hipStream_t s)
 {
-    if (sw == 16) hipLaunchKernelGGL((spmm_hub<16, WIDE>), grid, dim3(64), 0, s, a);
-    else if (sw == 64) hipLaunchKernelGGL((spmm_hub<64, WIDE>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((spmm_hub<32, WIDE>), grid, dim3(64), 0, s, a);
+    if (sw == 16) hipLaunchKernelGGL((spmm_hub<16, WIDE>), grid, dim3(64 * (1 + HubCfg<16>::L)), 0, s, a);
+    else if (sw == 64) hipLaunchKernelGGL((spmm_hub<64, WIDE>), grid, dim3(64 * (1 + HubCfg<64>::L)), 0, s, a);
+    else hipLaunchKernelGGL((spmm_hub<32, WIDE>), grid, dim3(64 * (1 + HubCfg<32>::L)), 0, s, a);
 }
 
 // Column-tile width of the rows / segment kernels when the caller leaves it to us (profiles/r02_wide_n_tiles.txt):
@@ -982,8 +970,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
             const int fr = side_stream(h, 0, s, &hs);
             if (fr != 0) return fr;
         }
-        if (h->hub_kernel == 1) { if (wide_hub) launch_hub<true>(sw, ha, hgrid, hs); else launch_hub<false>(sw, ha, hgrid, hs); }
-        else { if (wide_hub) launch_hub2<true>(sw, ha, hgrid, hs); else launch_hub2<false>(sw, ha, hgrid, hs); }
+        if (wide_hub) launch_hub<true>(sw, ha, hgrid, hs); else launch_hub<false>(sw, ha, hgrid, hs);
         ++launches;
     }
     if (h->n_chunks > 0) {

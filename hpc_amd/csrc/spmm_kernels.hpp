@@ -402,24 +402,26 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
     Vec<V>::template store<true>(a.C + (int64_t)L.row * a.ldc + col, acc);
 }
 
-// ---- hub kernel: rows longer than the split threshold, in STORED ORDER, fed through an LDS ring ---------------
-// A hub row is one fma chain per output column, tens of thousands of terms long.  The segment kernel above keeps at
-// most 32 B-row gathers in flight per chain (registers), i.e. ~47 ns per nonzero: a 64 K-nonzero hub alone would take
-// 3 ms.  Cutting the row into pieces (spmm_chunks + spmm_reduce_chunks, still available as "split_long_rows" = 1)
-// parallelises it but changes the summation order.  Here the order stays and the memory latency leaves the chain:
-//   * one WAVE per (hub row, slice of SW columns); the N/SW slices of a row are independent chains on different CUs;
-//   * everything the wave reads arrives by LDS-DMA (global_load_lds, no VGPR destination): per stage of 64 nonzeros
-//     one dword DMA for col_idx, one for vals and Q = 64*SW*4/1024 sixteen-byte DMAs for the B-row slices (lane l of
-//     instruction q fetches part l % (SW/4) of nonzero q*NPI + l / (SW/4): whole 64..256-byte row segments);
-//   * D stages of B rows are in flight at any time -- up to 63 wave-instructions, 56 KiB, 448 nonzeros at SW = 32 --
-//     where registers hold 32; the (col, val) pairs run a further D stages ahead because a stage's B addresses
-//     need its columns (read back from LDS);
-//   * the wave waits with a COUNTED s_waitcnt vmcnt (vector-memory operations retire in issue order): "all but the
-//     youngest (D-1) stages' worth" -- never vmcnt(0) inside the loop; hipcc does not see the DMA (inline asm), so no
-//     compiler-generated wait drains the ring, and the loop contains no other vector-memory instruction;
-//   * the chain itself: lane j owns column j of the slice, reads B[k][j] with ds_read_b32 and the value a_k as a
-//     broadcast ds_read_b128 (4 values), one v_fma_f32 per nonzero, k ascending: bit-identical to spmm_ref.cu:10-14.
-// Rate: ~4-5 ns per nonzero and slice against 47 (measured: profiles/r03_hub_*), the slices of a row in parallel.
+// ---- hub kernel: rows longer than the hub threshold, in STORED ORDER -------------------------------------------
+// A hub row is one fma chain per output column, tens of thousands of terms long.  The segment kernel above keeps at most
+// 32 B-row gathers in flight per chain (registers): ~47 ns per nonzero, 3 ms for a 64 K-nonzero hub.  Cutting the row
+// into pieces (spmm_chunks + spmm_reduce_chunks, still available as "split_long_rows" = 1) parallelises it but changes the
+// summation order.  Here the order stays and the memory latency leaves the chain.  One workgroup per (hub row, slice of SW
+// columns) -- the N / SW slices of a row are independent chains on different CUs -- made of ONE chain wave and L loader
+// waves.  (First form, commit d0af313: one wave per slice doing everything, fed by LDS-DMA -- ten DMA issues per 64
+// nonzeros at ~90 cycles each and 0.75 LDS reads per nonzero, because a DMA lands a B row as it is, [k][column], and a
+// lane's next value sits in another 16-byte granule: 28 cycles per nonzero; profiles/r03_hub_experiments.txt.)
+//   * a loader takes every L-th stage of 64 nonzeros: B-row slices by ordinary 16-byte global loads, U stages deep in
+//     registers (L x U x 8 KiB in flight per workgroup), and writes them to the LDS ring TRANSPOSED -- four loads of one
+//     lane are nonzeros k..k+3 of the same four columns, so a 4 x 4 register transpose (free: register naming) turns
+//     them into one ds_write_b128 per column: ring[column][k..k+3];
+//   * the chain wave owns one column per lane: ONE ds_read_b128 brings its next four B values, one broadcast
+//     ds_read_b128 the four a values: 0.5 LDS reads and one v_fma_f32 per nonzero, k ascending -- the same chain,
+//     bit for bit, as spmm_ref.cu:10-14;
+//   * hand-off through two kinds of LDS words: published[w] = stages loader w has written (loader -> chain wave) and done = stages consumed
+//     (chain wave -> loaders, so a slot is not overwritten early).  A wave's LDS operations execute in order, so a
+//     flag written after the data is seen after the data; no barrier inside the loop, one at kernel start.
+// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, the loaders' writes 2-way.
 struct HubArgs {
     const LongRow *rows;     // hub rows, longest first
     const int32_t *row_ptr;
@@ -435,165 +437,7 @@ struct HubArgs {
     int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are skipped (row panels)
 };
 
-// One wave-instruction of LDS-DMA: lane l's bytes land at lds_dst + 16 l (4 l for the dword form).  M0 carries the LDS
-// address; it is saved and restored inside the statement.
-__device__ __forceinline__ void glds16(uint32_t lds_dst, const void *sbase, uint32_t voff)   // SGPR base + 32-bit lane offset
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ void glds16w(uint32_t lds_dst, const void *addr)                  // 64-bit lane address
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(addr), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ void glds4w(uint32_t lds_dst, const void *addr)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(addr), "s"(lds_dst)
-                 : "memory");
-}
-
 template <int SW> struct HubCfg {
-    static constexpr int ST = 64;                  // nonzeros per stage
-    static constexpr int NPI = 256 / SW;           // nonzeros per B DMA instruction (64 lanes x 16 B = NPI slices of SW floats)
-    static constexpr int Q = ST / NPI;             // B DMA instructions per stage (SW 16 / 32 / 64: 4 / 8 / 16)
-    static constexpr int PER = Q + 2;              // ... plus the stage's col_idx and vals
-    static constexpr int D = SW == 64 ? 4 : SW == 32 ? 7 : 11;   // stages of B rows in flight: (D - 1) * PER <= 63, the widest counted wait
-    static constexpr int NB = D + 1;               // B ring: stage t is consumed while stage t + D lands
-    static constexpr int NP = 2 * D + 1;           // pair ring: pairs run 2 D stages ahead
-    static constexpr int B_BYTES = ST * SW * 4;
-    static constexpr int P_BYTES = 512;            // 64 columns, then 64 values
-    static constexpr int LDS_BYTES = NB * B_BYTES + NP * P_BYTES;
-    static_assert((D - 1) * PER <= 63, "vmcnt is a 6-bit counter");
-};
-
-// s_waitcnt vmcnt(BASE + STEP * r) for a wave-uniform r in [0, RMAX]: the immediate must be a constant
-template <int BASE, int STEP, int R> __device__ __forceinline__ void wait_vm_counted(int r)
-{
-    if constexpr (R == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
-    else {
-        if (r == R) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + STEP * R) : "memory");
-        else wait_vm_counted<BASE, STEP, R - 1>(r);
-    }
-}
-
-template <int SW, bool WIDE>
-__global__ __launch_bounds__(64) void spmm_hub(HubArgs a)
-{
-    typedef HubCfg<SW> K;
-    constexpr int D = K::D, NB = K::NB, NP = K::NP, Q = K::Q, NPI = K::NPI;
-    constexpr int LPS = SW / 4;                    // lanes (16-byte parts) per row slice
-    __shared__ __attribute__((aligned(16))) unsigned char ring[K::LDS_BYTES];   // ONE array: B stages, then pair stages
-    const int lane = threadIdx.x;
-    const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;   // the slices of one hub are neighbours in dispatch order
-    const int row = __builtin_amdgcn_readfirstlane(a.rows[hub].row);
-    if (row < a.row_lo || row >= a.row_hi) return;
-    const int beg = __builtin_amdgcn_readfirstlane(a.row_ptr[row]);
-    const int end = __builtin_amdgcn_readfirstlane(a.row_ptr[row + 1]);
-    const int len = end - beg;
-    if (len <= 0) return;                          // (hub rows are long; an empty one would have nothing to clamp to)
-    const int n_st = (len + K::ST - 1) / K::ST;
-    // loader role of this lane: 16-byte part `part` of nonzero `ni` of each B instruction.  A slice that sticks out past
-    // N (or a width that is no multiple of 4) shifts its last parts back to column N - 4: they re-fetch and recompute
-    // columns of their neighbours with identical bits (as in the rows kernel).
-    const int part = lane % LPS, ni = lane / LPS;
-    const int colf = min(slice * SW + 4 * part, a.N - 4);
-    const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colf * 4u;
-    const uint32_t lds_b = (uint32_t)(size_t)&ring[0];                 // low 32 bits of a shared-aperture address = the LDS offset
-    const uint32_t lds_p = lds_b + NB * K::B_BYTES;
-
-    auto issue_pairs = [&](int s) {                // stage s: its 64 columns and 64 values (past the row: the last pair again)
-        const int k = min(beg + K::ST * s + lane, end - 1);
-        const uint32_t dst = lds_p + (uint32_t)(s % NP) * K::P_BYTES;
-        glds4w(dst, a.col_idx + k);
-        glds4w(dst + 256, a.vals + k);
-    };
-    auto issue_b = [&](int s) {                    // stage s: its 64 B-row slices (needs the stage's columns in LDS)
-        const int32_t *cols = reinterpret_cast<const int32_t *>(&ring[NB * K::B_BYTES + (s % NP) * K::P_BYTES]);
-        const uint32_t dst = lds_b + (uint32_t)(s % NB) * K::B_BYTES;
-        int c[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) c[q] = cols[q * NPI + ni];     // all LDS reads first: one wait, not one per DMA
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            if (WIDE) glds16w(dst + q * 1024, a.B + (int64_t)c[q] * a.ldb + colf);
-            else glds16(dst + q * 1024, a.B, __umul24((uint32_t)c[q], ldb_bytes) + col_bytes);
-        }
-    };
-
-    // consumer role: lane j (mod SW) owns column j of the slice
-    const int cj = lane % SW;
-    float acc = 0.f;
-    auto consume = [&](int s, int cnt) {
-        const float *bs = reinterpret_cast<const float *>(&ring[(s % NB) * K::B_BYTES]) + cj;
-        const float *vs = reinterpret_cast<const float *>(&ring[NB * K::B_BYTES + (s % NP) * K::P_BYTES + 256]);
-        if (cnt == K::ST) {
-            // every LDS read of the stage first (64 values of this lane's column, 16 broadcast quads of a), then the 64
-            // dependent fmas with counted waits: one exposed LDS latency per stage
-            float b[K::ST];
-            float4v av[K::ST / 4];
-#pragma unroll
-            for (int u = 0; u < K::ST; ++u) b[u] = bs[u * SW];
-#pragma unroll
-            for (int i = 0; i < K::ST / 4; ++i) av[i] = *reinterpret_cast<const float4v *>(vs + 4 * i);
-#pragma unroll
-            for (int u = 0; u < K::ST; ++u) acc = __builtin_fmaf(b[u], av[u / 4][u % 4], acc);
-        } else {
-            for (int i = 0; i < cnt; ++i) acc = __builtin_fmaf(bs[i * SW], vs[i], acc);
-        }
-    };
-
-    // prologue: the pairs of stages 0 .. D-1, one full round trip, then -- as pseudo-iterations -D .. -1 of the loop
-    // below -- the pairs of stages D .. 2D-1 and the B rows of stages 0 .. D-1
-#pragma unroll
-    for (int s = 0; s < D; ++s) issue_pairs(s);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int s = 0; s < D; ++s) {
-        issue_pairs(s + D);
-        if (s < n_st) issue_b(s);
-    }
-    for (int t = 0; t < n_st; ++t) {
-        // Iteration j issued 2 pair instructions and, if stage j + D exists, Q B instructions.  Everything iteration
-        // t - D issued (B rows of stage t, pairs of stage t + D) must have landed; iterations t-D+1 .. t-1 may be in flight.
-        const int r = min(D - 1, n_st - 1 - t);
-        wait_vm_counted<2 * (D - 1), Q, D - 1>(r);
-        issue_pairs(t + 2 * D);
-        if (t + D < n_st) issue_b(t + D);
-        consume(t, min(K::ST, len - K::ST * t));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the wave has gone (the LDS would be someone else's)
-    if (lane < SW) {
-        const int col = min(slice * SW + 4 * (cj / 4), a.N - 4) + (cj & 3);
-        __builtin_nontemporal_store(acc, a.C + (int64_t)row * a.ldc + col);
-    }
-}
-
-// ---- hub kernel, second form: loader waves + one chain wave ---------------------------------------------------
-// spmm_hub (above) spends ~28 cycles per nonzero: the wave that runs the chain also issues ten LDS-DMA instructions
-// per 64 nonzeros (~90 cycles each with a deep queue) and needs 0.75 LDS reads per nonzero, because an LDS-DMA lands
-// a B row as it is ([k][column]: a lane's next value sits in another 16-byte granule).  Here a workgroup is ONE chain
-// wave and L loader waves:
-//   * a loader takes every L-th stage of 64 nonzeros: B-row slices by ordinary 16-byte global loads, U stages deep in
-//     registers (L x U x 8 KiB in flight per workgroup), and writes them to the LDS ring TRANSPOSED -- four loads of one
-//     lane are nonzeros k..k+3 of the same four columns, so a 4 x 4 register transpose (free: register naming) turns
-//     them into one ds_write_b128 per column: ring[column][k..k+3];
-//   * the chain wave owns one column per lane: ONE ds_read_b128 brings its next four B values, one broadcast
-//     ds_read_b128 the four a values: 0.5 LDS reads and one v_fma_f32 per nonzero, k ascending -- the same chain,
-//     bit for bit, as spmm_ref.cu:10-14;
-//   * hand-off through two kinds of LDS words: published[w] = stages loader w has written (loader -> chain wave) and done = stages consumed
-//     (chain wave -> loaders, so a slot is not overwritten early).  A wave's LDS operations execute in order, so a
-//     flag written after the data is seen after the data; no barrier inside the loop, one at kernel start.
-// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, the loaders' writes 2-way.
-template <int SW> struct Hub2Cfg {
     static constexpr int ST = 64;                  // nonzeros per stage
     static constexpr int L = 3;                    // loader waves
     static constexpr int U = 3;                    // stages each loader holds in registers
@@ -619,9 +463,9 @@ __device__ __forceinline__ void hub_flag_store(int *p, int v)
 }
 
 template <int SW, bool WIDE>
-__global__ __launch_bounds__(64 * (1 + Hub2Cfg<SW>::L)) void spmm_hub2(HubArgs a)
+__global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 {
-    typedef Hub2Cfg<SW> K;
+    typedef HubCfg<SW> K;
     constexpr int L = K::L, U = K::U, LPS = K::LPS, NG = K::NG, NBK = K::NBK, CS = K::CS, NB = K::NB;
     __shared__ __attribute__((aligned(16))) float ring[K::LDS_BYTES / 4];
     __shared__ int flags[16];                                   // [w] (w < L): stages loader w has published, in its own order; [L]: stages consumed
@@ -723,7 +567,9 @@ __global__ __launch_bounds__(64 * (1 + Hub2Cfg<SW>::L)) void spmm_hub2(HubArgs a
     // ---- loaders: wave w takes stages w, w + L, w + 2L, ...
     const int w = wave - 1;
     const int part = lane % LPS, g = lane / LPS;
-    const int colf = min(slice * SW + 4 * part, a.N - 4);     // parts past N shift back (see spmm_hub)
+    // A slice that sticks out past N (or a width that is no multiple of 4) shifts its last parts back to column N - 4: they
+    // re-fetch and recompute columns of their neighbours with identical bits (as in the rows kernel).
+    const int colf = min(slice * SW + 4 * part, a.N - 4);
     const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)colf * 4u;
     struct Pairs1 { int c; float v; };
     auto load_pairs = [&](int s) {

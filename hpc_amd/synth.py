@@ -133,9 +133,8 @@ def csr_block_dense(M, rows_per_block=16, run_lo=64, run_hi=128, max_runs=2, K=N
     return ptr.astype(np.int32), col_idx
 
 
-def csr_block_dense_fast(M, rows_per_block=16, K=None, seed=SEED_STRUCT):
-    """Vectorised C4 generator for M = 2^20: one or two aligned runs of 64 or 128 columns per
-    16-row block (same family as csr_block_dense, no Python loop over blocks)."""
+def _block_dense_fast_params(M, rows_per_block, K, seed):
+    """The per-block draws behind csr_block_dense_fast (cheap: one entry per 16-row block)."""
     K = M if K is None else K
     g = _rng(seed, 3)
     nb = (M + rows_per_block - 1) // rows_per_block
@@ -149,6 +148,13 @@ def csr_block_dense_fast(M, rows_per_block=16, K=None, seed=SEED_STRUCT):
     s2 = np.minimum(s1 + len1 + gap, (slots - 2) * align)   # second run never overlaps the first
     s2 = np.maximum(s2, s1 + len1)
     len2 = np.where(n_runs == 2, len2, 0)
+    return len1, len2, s1, s2
+
+
+def csr_block_dense_fast(M, rows_per_block=16, K=None, seed=SEED_STRUCT):
+    """Vectorised C4 generator for M = 2^20: one or two aligned runs of 64 or 128 columns per
+    16-row block (same family as csr_block_dense, no Python loop over blocks)."""
+    len1, len2, s1, s2 = _block_dense_fast_params(M, rows_per_block, K, seed)
     blk_len = (len1 + len2).astype(np.int64)
     deg = np.repeat(blk_len, rows_per_block)[:M]
     ptr = np.zeros(M + 1, dtype=np.int64)
@@ -161,6 +167,28 @@ def csr_block_dense_fast(M, rows_per_block=16, K=None, seed=SEED_STRUCT):
     in_first = pos < len1[b]
     col = np.where(in_first, s1[b] + pos, s2[b] + (pos - len1[b]))
     return ptr.astype(np.int32), col.astype(np.int32)
+
+
+def csr_block_dense_fast_device(M, device, rows_per_block=16, K=None, seed=SEED_STRUCT):
+    """csr_block_dense_fast with the expansion to 151 M nonzeros done on the device (torch): the same per-block draws, the
+    same row_ptr / col_idx (test_synth_device_generators_match), seconds instead of half a minute of host time.  Returns
+    device int32 tensors (row_ptr, col_idx)."""
+    import torch
+
+    len1, len2, s1, s2 = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(device)
+                          for a in _block_dense_fast_params(M, rows_per_block, K, seed))
+    deg = torch.repeat_interleave(len1 + len2, rows_per_block)[:M]
+    ptr = torch.zeros(M + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=ptr[1:])
+    nnz = int(ptr[-1].item())
+    assert nnz <= np.iinfo(np.int32).max
+    rows = torch.repeat_interleave(torch.arange(M, dtype=torch.int32, device=device), deg)
+    pos = torch.arange(nnz, dtype=torch.int32, device=device) - ptr[:-1].to(torch.int32)[rows.long()]
+    b = (rows // rows_per_block).long()
+    del rows
+    l1 = len1.to(torch.int32)[b]
+    col = torch.where(pos < l1, s1.to(torch.int32)[b] + pos, s2.to(torch.int32)[b] + (pos - l1))
+    return ptr.to(torch.int32), col
 
 
 def csr_rmat(scale, edge_factor=32, a=0.57, b=0.19, c=0.19, seed=SEED_STRUCT):

@@ -38,6 +38,22 @@ def test_single_gpu_line():
     assert d["ms_per_step_ref_protocol"] >= d["device_ms_per_step"] * 0.9      # util.h:141-151: 20 individually synchronised runs
     assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
     assert abs(d["value"] - 2.0 * d["config"]["nnz"] * d["config"]["N"] / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+    assert "l2_fabric" in r["bound_detail"] and "frac_of_measured_copy_6290" in r
+    # the other single-GPU BASELINE configurations ride in the same line (timed after the headline's region)
+    also = d["also"]
+    assert set(also) == {"C2", "C4", "C1_N1024"}
+    for k, e in also.items():
+        assert "error" not in e, (k, e)
+        for key in ("config", "ms_per_step", "value", "roofline", "steps", "summation_order"):
+            assert key in e, (k, key)
+        assert e["ms_per_step"] > 0 and e["value"] > 0 and e["steps"] == 3 and e["summation_order"].startswith("exact")
+        ro = e["roofline"]
+        for key in ("bound", "achieved", "peak", "frac", "bytes_min", "traffic", "traffic_source"):
+            assert key in ro, (k, key)
+        assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert also["C4"]["roofline"]["bound"] == "mfma" and also["C4"]["roofline"]["block_items"]["n_block_groups"] == 65536 // 16
+    assert also["C2"]["roofline"]["bound"] == "hbm" and also["C1_N1024"]["roofline"]["bound"] == "hbm"
+    assert "N=1024" in also["C1_N1024"]["config"] and "N=256" in also["C4"]["config"]
 
 
 @pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d"])

@@ -107,6 +107,34 @@ def test_oracle_reproduces_reference_kernel_goldens(oracle, path):
     assert np.array_equal(out2.view(np.uint32), exp.view(np.uint32))
 
 
+@pytest.mark.parametrize("path", _golden_files(), ids=lambda p: os.path.basename(p))
+def test_reference_kernel_body_built_for_the_host_reproduces_the_goldens(path):
+    """Provenance of the fixtures without a GPU: the reference's own 15 lines (spmm_ref.cu:3-17), compiled for the host by
+    oracle/Makefile `_ref_host` (g++ -mfma -ffp-contract=fast; the launch loop of SpMMRef::run around them), give the
+    fixtures' C_ref_kernel bit for bit.  The build reads the reference tree, so it happens only where that tree is (this
+    container); a prebuilt oracle/_ref/libspmm_ref_host.so is used as it stands; with neither the test is skipped."""
+    import ctypes
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_ref", "libspmm_ref_host.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref_host"])
+    if not os.path.exists(so):
+        pytest.skip("no reference tree and no prebuilt oracle/_ref/libspmm_ref_host.so here")
+    lib = ctypes.CDLL(so)
+    z = np.load(path)
+    ptr, idx = np.ascontiguousarray(z["row_ptr"], np.int32), np.ascontiguousarray(z["col_idx"], np.int32)
+    vals, B = np.ascontiguousarray(z["vals"], np.float32), np.ascontiguousarray(z["B"], np.float32)
+    M, N = ptr.size - 1, B.shape[1]
+    out = np.full((M, N), np.nan, np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.ref_host_spmm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int]
+    assert lib.ref_host_spmm(p(ptr), p(idx), p(vals), p(B), p(out), M, N) == 0
+    exp = z["C_ref_kernel"]
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), f"{(out.view(np.uint32) != exp.view(np.uint32)).sum()} of {out.size} differ"
+
+
 def test_philox4x32_10_known_answers(oracle):
     """Random123 kat_vectors for philox4x32-10: pins the generator behind mi_spmm_fill_normal."""
     assert oracle.philox_block([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
