@@ -211,6 +211,7 @@ def main():
                                               exchange="allgather", rehearse=args.rehearse_multi)
             if share:
                 exchange = "peer2d"    # RCCL refuses two ranks on one device: IPC copies + host barriers (rehearsal only)
+                sharded.set_option("external_barrier", 1)   # step() below brackets every run with synchronize + dist.barrier
             else:
                 sharded.init_comm()    # our own RCCL communicator (unique id broadcast over torch.distributed)
         except Exception as e:

@@ -74,7 +74,8 @@ struct mi_spmm_handle {
     int64_t block_share;       // most pieces per item (1 = no sharing; default 2)
     int64_t block_max_pieces;  // most pieces a group's list is cut into = most passes (1 = never cut)
     int64_t block_run_min;     // shortest run worth a piece of its own
-    BlockItem *d_blk_items;
+    BlockItem *d_blk_items;    // grow-only (capacity blk_items_cap items): kept across preprocess calls, released by destroy
+    size_t blk_items_cap;
     int32_t n_blk_items, n_blk_pieces, n_blk_passes, n_blk_shared_items;
     // preprocess temporaries (grow-only, kept across preprocess calls, released by destroy)
     Scratch scratch_a, scratch_b;
@@ -96,8 +97,6 @@ static void free_plan(mi_spmm_handle *h)
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_blk_flag) (void)hipFree(h->d_blk_flag);
     if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
-    if (h->d_blk_items) (void)hipFree(h->d_blk_items);
-    h->d_blk_items = nullptr;
     h->n_blk_items = h->n_blk_pieces = h->n_blk_passes = h->n_blk_shared_items = 0;
     std::memset(h->blk_launch, 0, sizeof(h->blk_launch));
     h->d_blk_flag = nullptr;
@@ -118,33 +117,55 @@ static int block_slab_width(int32_t N) { return N <= 0 ? 0 : (N % 256 == 0 ? 256
 static bool block_path_shape_ok(int32_t N) { return block_slab_width(N) != 0; }
 
 // Block path, second half of preprocess: the qualifying groups (d_blk_groups, either plan builder) are cut into
-// pieces on the device (analyze_group_runs: one wave per group, O(nnz / 16) reads); the pieces -- a few per
-// group -- come back to the host, which orders every pass's pieces by first column and forms the items:
-// run pieces with the same first column share their B rows (longest first, at most block_share per item, every
-// shared length a whole number of k batches so that no shared piece ends inside a batch).  O(groups log groups) on
-// the host, once per preprocess; untimed by the reference's harness (test_spmm.cu:58).
+// pieces on the device (analyze_group_runs: one wave per group, O(nnz / 16) reads); every pass's pieces are ordered by
+// first column and formed into items: run pieces with the same first column share their B rows (longest first, at most
+// block_share per item, every shared length a whole number of k batches so that no shared piece ends inside a batch).
+// On the device by default (preprocess_gpu.hip build_block_items_gpu: one radix sort, two scans, one 80-byte copy back);
+// the host assembler below -- the pieces come back, O(groups log groups) on one core: 8 ms for C4's 65 536 groups --
+// stays behind "gpu_preprocess" = 0 as the cross-check (test_gpu_and_host_plan_builders_agree: same items, same launches).
 static int build_block_items(mi_spmm_handle *h)
 {
     const int32_t ng = h->n_blk_groups;
     if (ng <= 0) return MI_SPMM_OK;
-    GroupPieces *d_gp = nullptr;
-    if (hipMalloc((void **)&d_gp, (size_t)ng * sizeof(GroupPieces)) != hipSuccess) return MI_SPMM_ENOMEM;
+    // the groups' pieces live in the first preprocess arena (build_plan_gpu is done with it): no allocation call here
+    if (scratch_reserve(&h->scratch_a, (size_t)ng * sizeof(GroupPieces) + 256) != 0) return MI_SPMM_ENOMEM;
+    GroupPieces *d_gp = reinterpret_cast<GroupPieces *>(h->scratch_a.p);
     hipLaunchKernelGGL(analyze_group_runs, dim3((unsigned)((ng + 3) / 4)), dim3(kBlockThreads), 0, 0, h->d_ptr, h->d_idx,
                        h->d_blk_groups, ng, (int32_t)h->block_max_pieces, (int32_t)h->block_run_min, d_gp);
     hipError_t e = hipGetLastError();
-    std::vector<GroupPieces> gp((size_t)ng);
-    std::vector<int32_t> groups((size_t)ng);
-    if (e == hipSuccess) e = hipMemcpy(gp.data(), d_gp, (size_t)ng * sizeof(GroupPieces), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(groups.data(), h->d_blk_groups, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(d_gp);
-    if (e != hipSuccess) return (int)e;
-
     // shared items need the two-piece kernels, which exist for 256- and 128-column slabs (N % 128 == 0)
     const int slab_w = block_slab_width(h->feat);
     const int share = slab_w >= 128 ? (int)h->block_share : 1;
     // the run kernels sweep whole trips (two k batches: 16 / 32 / 64 rows for 256- / 128- / narrower slabs) and fetch their A
     // operands 16 bytes at a time; a run of any other length goes through the list kernel (general lengths, dword A loads)
     const int run_unit = slab_w == 256 ? 16 : slab_w == 128 ? 32 : 64;
+    if (e == hipSuccess && h->gpu_preprocess) {
+        BlockPlanOut bo;
+        bo.d_items = h->d_blk_items;
+        bo.items_cap = h->blk_items_cap;
+        const int rc = build_block_items_gpu(d_gp, h->d_blk_groups, ng, share, run_unit, &h->scratch_b, &bo);
+        h->d_blk_items = bo.d_items;
+        h->blk_items_cap = bo.items_cap;
+        if (rc != MI_SPMM_OK) return rc;
+        h->n_blk_items = bo.n_items;
+        h->n_blk_pieces = bo.n_pieces;
+        h->n_blk_passes = bo.n_passes;
+        h->n_blk_shared_items = bo.n_shared;
+        h->ws_bytes += (size_t)bo.n_items * sizeof(BlockItem);
+        const int run_cls = share > 1 ? 2 : 1;     // run items of one and of two pieces share a launch where the two-piece kernels exist
+        for (int pass = 0; pass < kMaxPieces; ++pass) {
+            h->blk_launch[pass][0].off = bo.launch[pass][0].off;
+            h->blk_launch[pass][0].n = bo.launch[pass][0].n;
+            h->blk_launch[pass][run_cls].off = bo.launch[pass][1].off;
+            h->blk_launch[pass][run_cls].n = bo.launch[pass][1].n;
+        }
+        return MI_SPMM_OK;
+    }
+    std::vector<GroupPieces> gp((size_t)ng);
+    std::vector<int32_t> groups((size_t)ng);
+    if (e == hipSuccess) e = hipMemcpy(gp.data(), d_gp, (size_t)ng * sizeof(GroupPieces), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(groups.data(), h->d_blk_groups, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
 
     struct Key { int32_t col, len, gi, ord; bool shareable, run; };
     struct Launch { int32_t off, n; };
@@ -236,7 +257,20 @@ static int build_block_items(mi_spmm_handle *h)
         h->ws_bytes += bytes;
         return MI_SPMM_OK;
     };
-    int rc = upload((void **)&h->d_blk_items, items.data(), items.size() * sizeof(BlockItem));
+    if (h->blk_items_cap < items.size()) {
+        if (h->d_blk_items) (void)hipFree(h->d_blk_items);
+        h->d_blk_items = nullptr;
+        h->blk_items_cap = 0;
+    }
+    int rc = MI_SPMM_OK;
+    if (h->d_blk_items) {
+        const hipError_t ue = hipMemcpy(h->d_blk_items, items.data(), items.size() * sizeof(BlockItem), hipMemcpyHostToDevice);
+        if (ue != hipSuccess) rc = (int)ue;
+        else h->ws_bytes += items.size() * sizeof(BlockItem);
+    } else {
+        rc = upload((void **)&h->d_blk_items, items.data(), items.size() * sizeof(BlockItem));
+        if (rc == MI_SPMM_OK) h->blk_items_cap = items.size();
+    }
     if (rc != MI_SPMM_OK) return rc;
     h->n_blk_items = (int32_t)items.size();
     h->n_blk_pieces = (int32_t)n_pieces;
@@ -454,6 +488,7 @@ int mi_spmm_destroy(mi_spmm_handle *h)
     scratch_release(&h->scratch_a);
     scratch_release(&h->scratch_b);
     if (h->d_col_bad) (void)hipFree(h->d_col_bad);
+    if (h->d_blk_items) (void)hipFree(h->d_blk_items);
     for (int i = 0; i < 2; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -523,7 +558,10 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "block_path") *value = h->block_path;
     else if (k == "n_long_rows") *value = h->n_long;
     else if (k == "n_chunks") *value = h->n_chunks;
-    else if (k == "workspace_bytes") *value = (int64_t)h->ws_bytes;
+    else if (k == "workspace_bytes") *value = (int64_t)(h->ws_bytes + h->scratch_a.cap + h->scratch_b.cap);   // plan tables + partial sums + the two preprocess arenas (kept until destroy)
+    else if (k == "feat") *value = h->feat;
+    else if (k == "num_v") *value = h->num_v;
+    else if (k == "num_cols") *value = h->num_cols;
     else if (k == "max_row_nnz") *value = h->max_row_nnz;
     else if (k == "column_locality_pct") *value = h->local_pct;
     else if (k == "n_launches") *value = h->last_launches;

@@ -35,6 +35,7 @@ struct mi_spmm_dist {
     int64_t N_total = 0;
     int exchange = kAllGather;
     bool rehearse = false;                     // run the exchange machinery even at world == 1 (one-GPU rehearsal)
+    bool external_barrier = false;             // peer2d without a communicator: the CALLER brackets every step with a cross-rank barrier
     std::vector<std::pair<int32_t, int32_t>> panels;
     int32_t rows_max = 0;
     // streams / events (created on first use, on the device current at that time)
@@ -198,6 +199,10 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
     }
     if (d->exchange == kPeer2D) {
         if ((int)d->peer_C.size() != d->world || d->exported_C != d_C_full) return MI_SPMM_ESTATE;
+        // the two device-side barriers of a peer2d step are all-reduces on the communicator: without one, ranks would push
+        // into C_full buffers that may still be read, and nobody would know when the pushes have landed -- refuse, unless
+        // the caller has said that it brackets every step with a cross-rank barrier of its own ("external_barrier")
+        if (do_exchange && d->world > 1 && !d->comm && !d->external_barrier) return MI_SPMM_ESTATE;
     } else if (!d->comm) return MI_SPMM_ESTATE;
     MI_TRY(ensure_streams(d));
     MI_TRY(ensure_panel_events(d));
@@ -276,9 +281,14 @@ int mi_spmm_dist_create(mi_spmm_dist **out, mi_spmm_handle *h, int32_t num_v, in
     if (!out) return MI_SPMM_EINVAL;
     *out = nullptr;
     if (!h || num_v < 0 || n_loc < 0 || world < 1 || rank < 0 || rank >= world || n_panels < 1) return MI_SPMM_EINVAL;
-    int64_t prepared = 0;
+    int64_t prepared = 0, feat = 0, rows = 0;
     MI_TRY(mi_spmm_get_option(h, "prepared", &prepared));
     if (!prepared) return MI_SPMM_ESTATE;
+    // the operator must be THIS rank's: n_loc columns, num_v rows (a wider n_loc would exchange columns nobody computed,
+    // a smaller num_v would drop rows silently)
+    MI_TRY(mi_spmm_get_option(h, "feat", &feat));
+    MI_TRY(mi_spmm_get_option(h, "num_v", &rows));
+    if (feat != n_loc || rows != num_v) return MI_SPMM_EINVAL;
     mi_spmm_dist *d = new (std::nothrow) mi_spmm_dist();
     if (!d) return MI_SPMM_ENOMEM;
     d->h = h;
@@ -386,6 +396,7 @@ int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
     const std::string k(key);
     if (k == "exchange") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; d->exchange = (int)v; }
     else if (k == "rehearse") d->rehearse = v != 0;
+    else if (k == "external_barrier") d->external_barrier = v != 0;
     else if (k == "n_panels") {
         if (v < 1 || v > (1 << 20)) return MI_SPMM_EINVAL;
         (void)hipDeviceSynchronize();   // staging buffers of a step in flight
@@ -407,6 +418,7 @@ int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *val
     else if (k == "world") *value = d->world;
     else if (k == "rank") *value = d->rank;
     else if (k == "has_comm") *value = d->comm ? 1 : 0;
+    else if (k == "external_barrier") *value = d->external_barrier ? 1 : 0;
     else if (k == "has_peers") *value = (int)d->peer_C.size() == d->world ? 1 : 0;
     else if (k == "staging_bytes") *value = (int64_t)(2 * d->staging_elems * sizeof(float));
     else if (k == "bytes_sent_per_step") *value = moved;

@@ -66,4 +66,18 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                    const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, int32_t split,
                    Scratch *sa, Scratch *sb, PlanOut *out);
 
+// ---- block path: items assembled on the device ---------------------------------------------------
+// d_gp / d_groups: analyze_group_runs' output for the ng qualifying groups.  Pieces are ordered by (pass, list pieces before
+// run pieces, first column, shareable first, longest first, group) with one stable radix sort; run pieces with the same first
+// column form items of up to `share` pieces.  The result -- item array and launch table -- is what the host assembler
+// (mi_spmm.hip build_block_items_host, kept behind "gpu_preprocess" = 0) produces, record for record.
+struct BlockPlanOut {
+    BlockItem *d_items = nullptr;                       // in: the caller's grow-only item buffer (or null); out: the buffer that holds the items
+    size_t items_cap = 0;                               // in / out: its capacity in items (re-allocated only when too small)
+    int32_t n_items = 0, n_pieces = 0, n_passes = 0, n_shared = 0;
+    struct { int32_t off, n; } launch[kMaxPieces][2];   // [pass][0: list items, 1: run items]
+};
+int build_block_items_gpu(const GroupPieces *d_gp, const int32_t *d_groups, int32_t ng, int32_t share, int32_t run_unit, Scratch *sc,
+                          BlockPlanOut *out);
+
 }  // namespace mi

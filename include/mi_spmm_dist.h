@@ -26,8 +26,10 @@
  *                 copy (512-byte row segments at pitch 4*N_total; the peers' C_full are mapped through HIP IPC).
  *                 Per step and GPU this moves (world-1)/world of C once out and once in, and nothing else.
  * 0 and 1 need a communicator (mi_spmm_dist_comm_init); 2 needs the peers' C_full (mi_spmm_dist_set_peers) and,
- * to be self-synchronising, a communicator too (a one-element all-reduce is the end-of-step barrier); without
- * one the caller must put a cross-rank barrier after the step's stream work and before the next step.
+ * to be self-synchronising, a communicator too (a one-element all-reduce is the end-of-step barrier).  Without a
+ * communicator a peer2d step at world > 1 is refused (MI_SPMM_ESTATE) unless "external_barrier" = 1 says that the caller
+ * brackets every step with a cross-rank barrier of its own (after the previous step's consumers, and after the
+ * step's stream work has completed).
  *
  * Errors: 0 = ok; negative MI_SPMM_E* codes of mi_spmm.h; positive hipError_t; ncclResult_t r is returned as
  * MI_SPMM_DIST_ENCCL_BASE - r.  Never aborts.
@@ -49,8 +51,8 @@ extern "C" {
 
 typedef struct mi_spmm_dist mi_spmm_dist;
 
-/* h: a PREPROCESSED operator for this rank's n_loc = feat_in columns (mi_spmm_preprocess done); it stays owned by
- * the caller and must outlive the object.  n_panels: row panels per step (>= 1; panels are multiples of 256 rows). */
+/* h: a PREPROCESSED operator for this rank's n_loc = feat_in columns and num_v rows (mi_spmm_preprocess done; a handle
+ * of another shape is MI_SPMM_EINVAL); it stays owned by the caller and must outlive the object.  n_panels: row panels per step (>= 1; panels are multiples of 256 rows). */
 int mi_spmm_dist_create(mi_spmm_dist **out, mi_spmm_handle *h, int32_t num_v, int32_t n_loc, int32_t rank,
                         int32_t world, int32_t n_panels);
 int mi_spmm_dist_destroy(mi_spmm_dist *d);
@@ -69,7 +71,7 @@ int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, in
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
 /* keys: "exchange" (0 allgather, 1 direct, 2 peer2d), "n_panels", "rehearse" (1: run the staging / collective /
- * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path); read-only: "world", "rank", "has_comm",
+ * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path), "external_barrier" (see above); read-only: "world", "rank", "has_comm",
  * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step" */
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);
 int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *value);

@@ -123,6 +123,15 @@ def _native_worker(rank, world, port, M, n_loc, n_panels, kind, q):
         sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=n_panels, exchange="peer2d")
         sh.set_peers(C_full)
         assert sh.get_option("has_peers") == 1 and sh.get_option("has_comm") == 0
+        # no communicator: the step's two device-side barriers do not exist, so the library refuses to run it ...
+        from hpc_amd.dist import MiSpmmDistError
+        try:
+            sh.run(B_loc, C_full)
+            refused = False
+        except MiSpmmDistError as e:
+            refused = e.code == -3           # MI_SPMM_ESTATE
+        assert refused, "peer2d at world > 1 without a communicator must be refused"
+        sh.set_option("external_barrier", 1)     # ... unless the caller says it brackets every step itself (below)
 
         def barrier():
             torch.cuda.synchronize()

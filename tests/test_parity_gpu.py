@@ -652,6 +652,11 @@ def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
     op.set_option("long_row_threshold", 256)
     d_C = torch.full((M, 128), float("nan"), dtype=torch.float32, device=device)
     op.preprocess(d_B, d_C)
+    from hpc_amd.dist import MiSpmmDistError
+    for bad in (ShardLayout(M, 64, 1, 0), ShardLayout(M - 1, 128, 1, 0)):      # not this operator's columns / rows
+        with pytest.raises(MiSpmmDistError) as ei:
+            NativeColumnShardedSpMM(op, bad, n_panels=3, exchange=exchange)
+        assert ei.value.code == -1
     sh = NativeColumnShardedSpMM(op, ShardLayout(M, 128, 1, 0), n_panels=3, exchange=exchange, rehearse=True)
     sh.init_comm()
     if exchange == "peer2d":
@@ -989,13 +994,14 @@ def test_special_values_all_paths(device, oracle):
 
 
 def test_gpu_and_host_plan_builders_agree(device, oracle):
-    """the segment table built on the device (classify + scans + emit + radix sort) against
-    the reference-style host loop: same counts, same results, on hub-heavy, block and mixed structures."""
+    """the segment table and the block items built on the device (classify + scans + emit + radix sorts) against
+    the reference-style host loops: same counts, same launches, same results, on hub-heavy, block and mixed structures."""
     cases = {
         "rmat": synth.csr_rmat(15, 24, seed=4),
         "powerlaw": synth.csr_powerlaw(30000, 40.0, 3000, seed=4),
         "uniform": synth.csr_uniform(5000, 0, 50, seed=4),
         "blocks": _shared_list_case(50, 2500, 128, seed=44)[:2],
+        "block_runs": _run_groups_case(300, 5000, 128, seed=45, lens=(32, 48, 64, 96, 128, 33, 208, 16), slots=20)[:2],   # 1-3 passes, shared items, list pieces
         "single_row": (np.array([0, 5000], np.int32), np.arange(5000, dtype=np.int32)),
     }
     for name, (ptr, idx) in cases.items():
@@ -1009,7 +1015,10 @@ def test_gpu_and_host_plan_builders_agree(device, oracle):
                 C, op = run_spmm(device, ptr, idx, vals, B, options={"gpu_preprocess": gpu_pre, "long_row_threshold": thr,
                                                                     "long_row_chunk": 64, "split_long_rows": split})
                 res[gpu_pre] = (C, {k: op.get_option(k) for k in ("n_chunks", "n_long_rows", "n_hub_rows", "n_medium_rows", "n_partial_slots",
-                                                                  "n_block_groups", "max_row_nnz", "long_row_threshold")})
+                                                                  "n_block_groups", "max_row_nnz", "long_row_threshold", "n_block_items",
+                                                                  "n_block_pieces", "n_block_passes", "n_block_shared_items", "n_launches")})
+            if name == "block_runs":
+                assert res[1][1]["n_block_passes"] >= 2 and res[1][1]["n_block_shared_items"] > 0 and res[1][1]["n_block_items"] > 100
             assert res[1][1] == res[0][1], (name, thr, split, res[1][1], res[0][1])
             assert np.array_equal(bits(res[1][0]), bits(res[0][0])), (name, thr, split)
             t = res[1][1]["long_row_threshold"]
