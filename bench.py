@@ -56,11 +56,12 @@ def parse():
     ap.add_argument("--N", type=int, default=None, help="override dense columns per GPU")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--panels", type=int, default=8)
-    ap.add_argument("--exchange", default="allgather", choices=["auto", "allgather", "direct", "peer2d"],
+    ap.add_argument("--exchange", default="allgather", choices=["auto", "allgather", "direct", "peer2d", "peer_store"],
                     help="N>1: how the C blocks travel (include/mi_spmm_dist.h).  allgather = RCCL's collective into staging + "
                          "re-layout kernel (default); direct = all-pairs grouped ncclSend/ncclRecv into the same staging; peer2d = "
-                         "strided 2-D copies straight into the peers' C (HIP IPC), no staging, no re-layout; auto = time all "
-                         "three before the warm-up and keep the fastest (ranks agree collectively)")
+                         "strided 2-D copies straight into the peers' C (HIP IPC), no staging, no re-layout; peer_store = the kernels' epilogues "
+                         "store every result into the local C and into every peer's (no copies at all); auto = time all "
+                         "four before the warm-up and keep the fastest (ranks agree collectively)")
     ap.add_argument("--opt", action="append", default=[], help="key=value handle option (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="N=1, C1: skip the `also` object (C2, C4 and C1 at N=1024, timed after the headline)")
@@ -235,7 +236,7 @@ def main():
             ok, ms = 1.0, 0.0
             try:
                 sharded.set_exchange(name_)
-                if name_ == "peer2d":
+                if name_ in ("peer2d", "peer_store"):
                     sharded.set_peers(d_Cfull)
                 sharded.run(d_B, d_Cfull)
                 torch.cuda.synchronize()
@@ -254,7 +255,7 @@ def main():
 
         if world > 1 and not share and exchange == "auto" and sharded is not None:
             tuning = {}
-            for cand in ("allgather", "direct", "peer2d"):
+            for cand in ("allgather", "direct", "peer2d", "peer_store"):
                 ok, ms = try_exchange(cand)
                 tuning[cand] = round(ms, 4) if ok else None
             if tuning["allgather"] is None:
@@ -264,7 +265,7 @@ def main():
             exchange = "allgather"
         if sharded is not None:
             sharded.set_exchange(exchange)
-            if exchange == "peer2d":
+            if exchange in ("peer2d", "peer_store"):
                 sharded.set_peers(d_Cfull)
 
     def step():

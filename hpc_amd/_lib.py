@@ -22,6 +22,7 @@ SIGNATURES = {
     "mi_spmm_run": (C.c_int, [_P, _P, _P, _P]),
     "mi_spmm_run_ld": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P]),
     "mi_spmm_run_rows": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "mi_spmm_run_rows_multi": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mi_spmm_destroy": (C.c_int, [_P]),
     "mi_spmm_strerror": (C.c_char_p, [C.c_int]),
     "mi_spmm_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),

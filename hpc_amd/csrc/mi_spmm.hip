@@ -937,8 +937,11 @@ struct FullView { const float *B; float *C; int32_t N; };
 
 static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc, int32_t row_begin,
                     int32_t row_end, hipStream_t s, int32_t N, int64_t col0, bool blocks_on, bool launch_blocks_here,
-                    const FullView &full, int *launches_out, bool record)
+                    const FullView &full, int *launches_out, bool record, const PeerOut &po_full)
 {
+    // the extra destinations as this column part sees them (the hub and block kernels address the full width: po_full)
+    PeerOut po = po_full;
+    for (int q = 0; q < po.n; ++q) po.p[q] += col0;
     const int32_t M = h->num_v;
     // 16 bytes per lane whenever a row holds at least one float4: global dwordx4 accesses only need dword
     // alignment, and a row whose width is not a multiple of 4 gets its last lane shifted back to column N - 4
@@ -996,6 +999,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ha.N = full.N;
         ha.row_lo = row_begin;
         ha.row_hi = row_end;
+        ha.po = po_full;
         const int sw = h->hub_slice > 0 ? (int)h->hub_slice : (full.N <= 16 ? 16 : 32);
         const bool wide_hub = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
                                 ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
@@ -1027,6 +1031,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ca.flags = flags;
         ca.row_lo = row_begin;
         ca.row_hi = row_end;
+        ca.po = po;
         const int cgpb = kBlockThreads / lpr;  // the chunk kernel always runs 256-thread workgroups
         dim3 cgrid((h->n_chunks + cgpb - 1) / cgpb, col_tiles);
         // partial rows are ldp (multiple of 4) floats and hipMalloc-aligned, so only
@@ -1059,6 +1064,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ba.remap = remap_blocks ? 1 : 0;
         ba.row_lo = row_begin;
         ba.row_hi = row_end;
+        ba.po = po_full;
         const int slab = block_slab_width(full.N), slabs = full.N / slab;
         // pass p continues the fma chains pass p-1 left in C: stream order is the dependency
         for (int pass = 0; pass < h->n_blk_passes; ++pass) {
@@ -1094,6 +1100,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     a.long_thr = (int32_t)(blocks_fallback ? h->long_thr : h->medium_res);
     a.nblk = (int)nblk64;
     a.flags = flags;
+    a.po = po;
     dim3 grid((unsigned)nblk64, col_tiles);
     // every row may already be owned by the segment, split and block paths: nothing left to launch
     const bool rows_needed = !((blocks_on || h->n_blk_groups == 0) && h->n_rows_for_rows_kernel == 0);
@@ -1113,6 +1120,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ra.flags = flags;
         ra.row_lo = row_begin;
         ra.row_hi = row_end;
+        ra.po = po;
         const int64_t threads = (int64_t)h->n_long * ((N + V - 1) / V);
         dim3 rgrid((unsigned)((threads + kBlockThreads - 1) / kBlockThreads));
         hipStream_t cs = s;       // behind the segment kernel that produced the partial sums
@@ -1140,15 +1148,30 @@ extern "C" {
 int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc,
                      int32_t row_begin, int32_t row_end, void *stream)
 {
+    return mi_spmm_run_rows_multi(h, d_vin, ldb, d_vout, ldc, row_begin, row_end, 0, nullptr, stream);
+}
+
+int mi_spmm_run_rows_multi(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc,
+                           int32_t row_begin, int32_t row_end, int32_t n_extra, float *const *d_extra, void *stream)
+{
     if (!good(h) || !h->prepared) return MI_SPMM_ESTATE;
+    if (n_extra < 0 || n_extra > kMaxPeerOut || (n_extra > 0 && !d_extra)) return MI_SPMM_EINVAL;
+    PeerOut po;
+    std::memset(&po, 0, sizeof(po));
+    po.n = n_extra;
+    for (int q = 0; q < n_extra; ++q) {
+        if (!d_extra[q]) return MI_SPMM_EINVAL;
+        po.p[q] = d_extra[q];
+    }
     const int32_t M = h->num_v, N = h->feat;
     if (row_begin < 0 || row_end > M || row_begin > row_end) return MI_SPMM_EINVAL;
     if (row_begin == row_end || N == 0) return MI_SPMM_OK;
     if (!d_vout || ldc < N || ldb < N) return MI_SPMM_EINVAL;
     if (!d_vin && h->nnz > 0) return MI_SPMM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const bool aligned16 = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
-                           (((uintptr_t)d_vin | (uintptr_t)d_vout) & 15u) == 0;
+    bool aligned16 = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
+                     (((uintptr_t)d_vin | (uintptr_t)d_vout) & 15u) == 0;
+    for (int q = 0; q < n_extra; ++q) aligned16 = aligned16 && ((uintptr_t)d_extra[q] & 15u) == 0;
     const bool blocks_on = h->n_blk_groups > 0 && aligned16;
     const FullView full = {d_vin, d_vout, N};
     // Widths just above a multiple of 256: the last 256-column tile would hold only a few columns yet run one
@@ -1159,10 +1182,10 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *
     if (rem > 64) rem = 0;
     int launches = 0;
     h->fork_recorded = h->forked[0] = h->forked[1] = false;
-    int rc = run_part(h, d_vin, ldb, d_vout, ldc, row_begin, row_end, s, N - rem, 0, blocks_on, true, full, &launches, true);
+    int rc = run_part(h, d_vin, ldb, d_vout, ldc, row_begin, row_end, s, N - rem, 0, blocks_on, true, full, &launches, true, po);
     if (rc == 0 && rem > 0)
         rc = run_part(h, d_vin + (N - rem), ldb, d_vout + (N - rem), ldc, row_begin, row_end, s, rem, N - rem, blocks_on,
-                      false, full, &launches, false);
+                      false, full, &launches, false, po);
     for (int i = 0; i < 2; ++i) {      // join: whatever the caller enqueues next is ordered after the side streams' rows too
         if (!h->forked[i]) continue;
         h->forked[i] = false;

@@ -20,7 +20,7 @@
 
 namespace {
 
-enum { kAllGather = 0, kDirect = 1, kPeer2D = 2 };
+enum { kAllGather = 0, kDirect = 1, kPeer2D = 2, kPeerStore = 3 };
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define NCCL_TRY(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return MI_SPMM_DIST_ENCCL_BASE - (int)r_; } while (0)
@@ -197,8 +197,9 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
         if (do_compute) return mi_spmm_run_rows(d->h, d_B_loc, n_loc, d_C_full, NT, 0, d->M, (void *)main);
         return 0;
     }
-    if (d->exchange == kPeer2D) {
+    if (d->exchange == kPeer2D || d->exchange == kPeerStore) {
         if ((int)d->peer_C.size() != d->world || d->exported_C != d_C_full) return MI_SPMM_ESTATE;
+        if (d->exchange == kPeerStore && d->world - 1 > 7) return MI_SPMM_EUNSUPPORTED;   // mi_spmm_run_rows_multi: at most 7 extra destinations
         // the two device-side barriers of a peer2d step are all-reduces on the communicator: without one, ranks would push
         // into C_full buffers that may still be read, and nobody would know when the pushes have landed -- refuse, unless
         // the caller has said that it brackets every step with a cross-rank barrier of its own ("external_barrier")
@@ -209,6 +210,30 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
     HIP_TRY(hipEventRecord(d->ev_start, main));
     HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_start, 0));   // earlier work on the caller's stream (readers of C_full, staging)
 
+    if (d->exchange == kPeerStore) {
+        // The kernels' epilogues store every finished row segment into the local C_full AND into every peer's (IPC-mapped):
+        // no copy, no staging, no re-layout, nothing to pipeline -- one launch set over all rows between two barriers.
+        float *own = d_C_full + (size_t)d->rank * (size_t)n_loc;
+        float *extra[8];
+        int n_extra = 0;
+        if (do_exchange)
+            for (int q = 0; q < d->world; ++q)
+                if (q != d->rank) extra[n_extra++] = d->peer_C[(size_t)q] + (size_t)d->rank * (size_t)n_loc;
+        if (do_exchange) {
+            MI_TRY(device_barrier(d, d->s_comm));                   // nobody still reads the C_full we are about to store into
+            HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));
+            HIP_TRY(hipStreamWaitEvent(main, d->ev_gathered[0], 0));
+        }
+        if (do_compute) MI_TRY(mi_spmm_run_rows_multi(d->h, d_B_loc, n_loc, own, NT, 0, d->M, n_extra, extra, (void *)main));
+        if (do_exchange) {
+            HIP_TRY(hipEventRecord(d->ev_computed[0], main));
+            HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_computed[0], 0));
+            MI_TRY(device_barrier(d, d->s_comm));                   // every rank's stores have landed (a finished kernel's stores are visible)
+            HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));
+            HIP_TRY(hipStreamWaitEvent(main, d->ev_gathered[0], 0));
+        }
+        return 0;
+    }
     if (d->exchange == kPeer2D) {
         MI_TRY(ensure_push_streams(d));
         // nobody may still be consuming the C_full we are about to overwrite remotely
@@ -394,7 +419,7 @@ int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
 {
     if (!good(d) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
-    if (k == "exchange") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; d->exchange = (int)v; }
+    if (k == "exchange") { if (v < 0 || v > 3) return MI_SPMM_EINVAL; d->exchange = (int)v; }
     else if (k == "rehearse") d->rehearse = v != 0;
     else if (k == "external_barrier") d->external_barrier = v != 0;
     else if (k == "n_panels") {
@@ -420,7 +445,7 @@ int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *val
     else if (k == "has_comm") *value = d->comm ? 1 : 0;
     else if (k == "external_barrier") *value = d->external_barrier ? 1 : 0;
     else if (k == "has_peers") *value = (int)d->peer_C.size() == d->world ? 1 : 0;
-    else if (k == "staging_bytes") *value = (int64_t)(2 * d->staging_elems * sizeof(float));
+    else if (k == "staging_bytes") *value = (d->exchange == kPeer2D || d->exchange == kPeerStore) ? 0 : (int64_t)(2 * d->staging_elems * sizeof(float));
     else if (k == "bytes_sent_per_step") *value = moved;
     else if (k == "bytes_received_per_step") *value = moved;
     else return MI_SPMM_EUNSUPPORTED;

@@ -21,6 +21,14 @@ struct LongRow {            // a row longer than the split threshold (a hub)
     int32_t len;            // nonzeros in the row
 };
 
+// ---- extra destinations of every finished C row segment (multi-GPU "peer_store" exchange: the peers' C, mapped through HIP IPC)
+constexpr int kMaxPeerOut = 7;
+struct PeerOut {
+    float *p[kMaxPeerOut];      // same layout as the local C (same pitch, same column offset already applied)
+    int32_t n;                  // 0 (every single-GPU call) .. kMaxPeerOut
+    int32_t pad;
+};
+
 // ---- block (MFMA) path ---------------------------------------------------------------------------
 constexpr int kMaxPieces = 4;     // most pieces (= passes) a group's column list is cut into
 constexpr int kShareLenUnit = 32; // a run piece is shared only if its length is a multiple of this (two of the kernels' largest k batches)

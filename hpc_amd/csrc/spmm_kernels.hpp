@@ -46,6 +46,7 @@ struct RowsArgs {
     int32_t nblk;           // gridDim.x (for the XCD remap)
     int32_t flags;          // kFlagXcdRemap
     const uint8_t *blk_flag; // per 16-row group: 1 = owned by the block (MFMA) path; may be null
+    PeerOut po;
 };
 
 enum : int32_t { kFlagXcdRemap = 4 };
@@ -106,6 +107,17 @@ template <> struct Vec<1> {
     static __device__ __forceinline__ T fma(T b, float a, T acc) { return __builtin_fmaf(b, a, acc); }
     static __device__ __forceinline__ T add(T a, T b) { return a + b; }
 };
+
+// A finished piece of C goes to the local C and to every extra destination (the peers' C of the multi-GPU "peer_store"
+// exchange; po.n == 0 on every single-GPU call: one uniform compare).  Same element offset everywhere: the buffers have one layout.
+template <int V, bool NT>
+__device__ __forceinline__ void store_c_all(float *C, const PeerOut &po, int64_t off, typename Vec<V>::T v)
+{
+    Vec<V>::template store<NT>(C + off, v);
+#pragma unroll
+    for (int q = 0; q < kMaxPeerOut; ++q)
+        if (q < po.n) Vec<V>::template store<NT>(po.p[q] + off, v);
+}
 
 // Broadcast lane j of the LPR-lane group this lane belongs to.
 template <int LPR>
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
         if (live) {
             acc = item_chain<V, LPR, PV, UNROLL, WIDE>(cur, min(CH, end - k0), acc, a.B, a.ldb, ldb_bytes, col_bytes, col);
             if (last) {
-                if (col_ok) Vec<V>::template store<(POL & kPolNtStore) != 0>(a.C + (int64_t)(gbase + ri) * a.ldc + col, acc);
+                if (col_ok) store_c_all<V, (POL & kPolNtStore) != 0>(a.C, a.po, (int64_t)(gbase + ri) * a.ldc + col, acc);
                 acc = Vec<V>::zero();
             }
         }
@@ -336,6 +348,7 @@ struct ChunkArgs {
     int32_t N;
     int32_t flags;
     int32_t row_lo, row_hi;  // only segments of rows in [row_lo, row_hi) are computed (row panels)
+    PeerOut po;
 };
 
 template <int V, int LPR, int UNROLL, bool WIDE>
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
         segment_chain_v2<V, LPR, UNROLL, WIDE, false>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
     if (col_ok) {
         if (c.slot >= 0) Vec<V>::template store<false>(a.partials + (int64_t)c.slot * a.ldp + col, acc);
-        else Vec<V>::template store<true>(a.C + (int64_t)c.row * a.ldc + col, acc);
+        else store_c_all<V, true>(a.C, a.po, (int64_t)c.row * a.ldc + col, acc);
     }
 }
 
@@ -376,6 +389,7 @@ struct ReduceArgs {
     int32_t N;
     int32_t flags;
     int32_t row_lo, row_hi;
+    PeerOut po;
 };
 
 template <int V>
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
         for (int u = 0; u < 8; ++u) acc = Vec<V>::add(acc, t[u]);
     }
     for (; i < L.n_chunks; ++i) acc = Vec<V>::add(acc, Vec<V>::load(p + (int64_t)i * a.ldp));
-    Vec<V>::template store<true>(a.C + (int64_t)L.row * a.ldc + col, acc);
+    store_c_all<V, true>(a.C, a.po, (int64_t)L.row * a.ldc + col, acc);
 }
 
 // ---- hub kernel: rows longer than the hub threshold, in STORED ORDER -------------------------------------------
@@ -435,6 +449,7 @@ struct HubArgs {
     int32_t N;
     int32_t slices;          // ceil(N / SW); gridDim.x = slices * n_hubs
     int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are skipped (row panels)
+    PeerOut po;
 };
 
 template <int SW> struct HubCfg {
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
         }
         if (lane < SW) {
             const int col = min(slice * SW + 4 * (cj / 4), a.N - 4) + (cj & 3);
-            __builtin_nontemporal_store(acc, a.C + (int64_t)row * a.ldc + col);
+            store_c_all<1, true>(a.C, a.po, (int64_t)row * a.ldc + col, acc);
         }
         return;
     }
@@ -707,6 +722,7 @@ struct BlockArgs {
     int32_t N;
     int32_t remap;           // 1: XCD remap of blockIdx.x (the item list is ordered by first column)
     int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are neither loaded nor stored; pieces wholly outside are skipped
+    PeerOut po;              // final tiles go there too; a tile a later pass continues stays local
 };
 
 typedef float float4a __attribute__((ext_vector_type(4)));
@@ -997,9 +1013,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
                             BV v;
 #pragma unroll
                             for (int e = 0; e < V; ++e) v[e] = acc[j][V * x + e][q];
-                            BV *dst = reinterpret_cast<BV *>(a.C + (int64_t)row * a.ldc + colv + CW * x);
-                            if (carried) *dst = v;
-                            else __builtin_nontemporal_store(v, dst);
+                            const int64_t off = (int64_t)row * a.ldc + colv + CW * x;
+                            if (carried) *reinterpret_cast<BV *>(a.C + off) = v;
+                            else {
+                                __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.C + off));
+#pragma unroll
+                                for (int pq = 0; pq < kMaxPeerOut; ++pq)
+                                    if (pq < a.po.n) __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.po.p[pq] + off));
+                            }
                         }
                     }
                 }

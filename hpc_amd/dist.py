@@ -263,7 +263,7 @@ _DIST_SIGNATURES = {
 }
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
-EXCHANGE_CODES = {"allgather": 0, "direct": 1, "peer2d": 2}
+EXCHANGE_CODES = {"allgather": 0, "direct": 1, "peer2d": 2, "peer_store": 3}
 
 
 class MiSpmmDistError(RuntimeError):

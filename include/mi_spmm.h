@@ -98,6 +98,16 @@ int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb,
                      float *d_vout, int64_t ldc, int32_t row_begin,
                      int32_t row_end, void *stream);
 
+/* Same, and every finished row segment of C is ALSO stored at the same element offset of n_extra (<= 7) further buffers
+ * of the same layout (same pitch ldc; d_extra[i] points where d_vout points in its buffer).  This is the multi-GPU
+ * "peer_store" exchange (include/mi_spmm_dist.h): the extra buffers are the peers' C, mapped through HIP IPC, and the
+ * kernels' epilogues write every result once locally and once per peer -- no staging, no copy, no re-layout.
+ * Chains a later block pass continues (carried tiles) stay local.  No reference counterpart. */
+int mi_spmm_run_rows_multi(mi_spmm_handle *h, const float *d_vin, int64_t ldb,
+                           float *d_vout, int64_t ldc, int32_t row_begin,
+                           int32_t row_end, int32_t n_extra, float *const *d_extra,
+                           void *stream);
+
 /* Replaces SpMMOpt::~SpMMOpt (include/spmm_opt.h:18-20). */
 int mi_spmm_destroy(mi_spmm_handle *h);
 

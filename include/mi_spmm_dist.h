@@ -25,7 +25,13 @@
  *                 world*n_loc) and pushes the panel into every peer's C_full with a strided 2-D device-to-device
  *                 copy (512-byte row segments at pitch 4*N_total; the peers' C_full are mapped through HIP IPC).
  *                 Per step and GPU this moves (world-1)/world of C once out and once in, and nothing else.
- * 0 and 1 need a communicator (mi_spmm_dist_comm_init); 2 needs the peers' C_full (mi_spmm_dist_set_peers) and,
+ *   3  peer_store the kernels' epilogues store every finished row segment into the local C_full AND into every peer's
+ *                 (mi_spmm_run_rows_multi; the peers' C_full mapped through HIP IPC as for peer2d): no copy engine, no
+ *                 staging, no re-layout -- the remote stores never touch local memory, so per step and GPU the local
+ *                 memory system carries the gather (18.0 GB at C3) plus what the peers store INTO it (3.76 GB) and nothing
+ *                 else: the only schedule whose byte budget allows the north star's >= 6x at 8 GPUs.
+ *                 One launch set over all rows between two barriers; world <= 8.
+ * 0 and 1 need a communicator (mi_spmm_dist_comm_init); 2 and 3 need the peers' C_full (mi_spmm_dist_set_peers) and,
  * to be self-synchronising, a communicator too (a one-element all-reduce is the end-of-step barrier).  Without a
  * communicator a peer2d step at world > 1 is refused (MI_SPMM_ESTATE) unless "external_barrier" = 1 says that the caller
  * brackets every step with a cross-rank barrier of its own (after the previous step's consumers, and after the
@@ -70,7 +76,7 @@ int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm);
 int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out);
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
-/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d), "n_panels", "rehearse" (1: run the staging / collective /
+/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d, 3 peer_store), "n_panels", "rehearse" (1: run the staging / collective /
  * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path), "external_barrier" (see above); read-only: "world", "rank", "has_comm",
  * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step" */
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);

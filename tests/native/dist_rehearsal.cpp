@@ -48,8 +48,8 @@ int main()
 
     hipStream_t stream;
     CK(hipStreamCreate(&stream));
-    const char *names[3] = {"allgather", "direct", "peer2d"};
-    for (int ex = 0; ex < 3; ++ex) {
+    const char *names[4] = {"allgather", "direct", "peer2d", "peer_store"};
+    for (int ex = 0; ex < 4; ++ex) {
         mi_spmm_dist *d = nullptr;
         CK(mi_spmm_dist_create(&d, h, M, N, /*rank*/ 0, /*world*/ 1, /*panels*/ 4));
         char id[MI_SPMM_DIST_UNIQUE_ID_BYTES];
@@ -57,7 +57,7 @@ int main()
         CK(mi_spmm_dist_comm_init(d, id));
         CK(mi_spmm_dist_set_option(d, "exchange", ex));
         CK(mi_spmm_dist_set_option(d, "rehearse", 1));
-        if (ex == 2) {
+        if (ex >= 2) {
             char handle[MI_SPMM_DIST_IPC_HANDLE_BYTES];
             int64_t off = 0;
             CK(mi_spmm_dist_export_c(d, d_C, handle, &off));     // a multi-rank host all-gathers handles and offsets

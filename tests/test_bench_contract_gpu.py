@@ -56,13 +56,13 @@ def test_single_gpu_line():
     assert "N=1024" in also["C1_N1024"]["config"] and "N=256" in also["C4"]["config"]
 
 
-@pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d"])
+@pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d", "peer_store"])
 def test_multi_gpu_path_rehearsal(exchange):
     d = _run("--rehearse-multi", "--no-cpu-baseline", "--check", "--panels", "3", "--exchange", exchange)
     assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
     b = d["multi_gpu_breakdown"]
     assert "error" not in b and b["compute_only_ms"] > 0 and b["exchange_only_ms"] > 0 and b["exchange"] == exchange
-    assert (b["staging_bytes"] > 0) == (exchange != "peer2d") and "strong_reference_ms" in d and d["strong_reference_ms"] > 0
+    assert (b["staging_bytes"] > 0) == (exchange not in ("peer2d", "peer_store")) and "strong_reference_ms" in d and d["strong_reference_ms"] > 0
     assert d["cpu_baseline"] is None
     r = d["roofline"]        # N>1: the same per-GPU kernel, timed on the compute-only leg
     assert r["bound"] == "hbm" and r["traffic"] is None and abs(r["kernel_ms"] - b["compute_only_ms"]) < 1e-3

@@ -92,10 +92,11 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_gpu_result(world, M, n_loc, 
 
 
 # ---- the same check through the C ABI of include/mi_spmm_dist.h (hpc_amd/libmi_spmm_dist.so) ----
-def _native_worker(rank, world, port, M, n_loc, n_panels, kind, q):
+def _native_worker(rank, world, port, M, n_loc, n_panels, kind, exchange, q):
     """exchange "peer2d": every rank maps the other ranks' C_full through HIP IPC (here: other processes on the same
     GPU) and pushes its column block into them with strided 2-D copies; no staging, no re-layout kernel, the rank's own
-    block is computed straight into its C_full.  RCCL cannot put two ranks on one device, so the end-of-step barrier
+    block is computed straight into its C_full.  exchange "peer_store": no copies either -- the kernels' epilogues store
+    every finished row segment into the local C_full and into every peer's (mi_spmm_run_rows_multi).  RCCL cannot put two ranks on one device, so the end-of-step barrier
     is the caller's (gloo) instead of the library's one-element all-reduce."""
     import torch
     import torch.distributed as dist
@@ -120,7 +121,7 @@ def _native_worker(rank, world, port, M, n_loc, n_panels, kind, q):
         C_full = torch.full((M, n_loc * world), float("nan"), device=dev)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
         op.preprocess(B_loc, C_full)
-        sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=n_panels, exchange="peer2d")
+        sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=n_panels, exchange=exchange)
         sh.set_peers(C_full)
         assert sh.get_option("has_peers") == 1 and sh.get_option("has_comm") == 0
         # no communicator: the step's two device-side barriers do not exist, so the library refuses to run it ...
@@ -156,14 +157,15 @@ def _native_worker(rank, world, port, M, n_loc, n_panels, kind, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["peer2d", "peer_store"])
 @pytest.mark.parametrize("world,M,n_loc,n_panels,kind", [(2, 40000, 128, 8, "uniform"), (3, 30011, 64, 5, "powerlaw")])
-def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n_panels, kind):
+def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n_panels, kind, exchange):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_native_worker, args=(r, world, port, M, n_loc, n_panels, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, M, n_loc, n_panels, kind, exchange, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:

@@ -630,7 +630,7 @@ def test_gather_pipeline_on_gpu_streams(device, oracle):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d"])
+@pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d", "peer_store"])
 def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
     """include/mi_spmm_dist.h on one GPU: a world of one with "rehearse" on runs the whole N > 1 machinery -- our own RCCL
     communicator (ncclCommInitRank from a unique id), the panel pipeline over three streams, the in-place all-gather /
@@ -659,7 +659,7 @@ def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
         assert ei.value.code == -1
     sh = NativeColumnShardedSpMM(op, ShardLayout(M, 128, 1, 0), n_panels=3, exchange=exchange, rehearse=True)
     sh.init_comm()
-    if exchange == "peer2d":
+    if exchange in ("peer2d", "peer_store"):
         sh.set_peers(d_C)
     assert sh.get_option("has_comm") == 1 and sh.get_option("n_panels") == 3
     for _ in range(3):
@@ -667,14 +667,14 @@ def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
     torch.cuda.synchronize()
     exp = oracle.spmm_omp(ptr, idx, vals, B)
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
-    assert (sh.get_option("staging_bytes") > 0) == (exchange != "peer2d")
+    assert (sh.get_option("staging_bytes") > 0) == (exchange not in ("peer2d", "peer_store"))
     # the two legs on their own (bench.py's breakdown: timing legs; with staging the panels share two buffers, so only
     # the staging-free exchange leaves a complete C behind)
     d_C.fill_(float("nan"))
     sh.run_compute_only(d_B, d_C)
     sh.run_exchange_only(d_C)
     torch.cuda.synchronize()
-    if exchange == "peer2d":
+    if exchange in ("peer2d", "peer_store"):
         assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
     sh.set_option("n_panels", 1)
     d_C.fill_(float("nan"))
@@ -693,7 +693,7 @@ def test_native_dist_cpp_rehearsal(device):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "native")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    for ex in ("allgather", "direct", "peer2d"):
+    for ex in ("allgather", "direct", "peer2d", "peer_store"):
         assert f"exchange {ex}: bit-identical" in r.stdout, r.stdout
 
 
