@@ -20,7 +20,7 @@
 
 namespace {
 
-enum { kAllGather = 0, kDirect = 1, kPeer2D = 2, kPeerStore = 3 };
+enum { kAllGather = 0, kDirect = 1, kPeer2D = 2, kPeerStore = 3, kIpcPull = 4 };
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define NCCL_TRY(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return MI_SPMM_DIST_ENCCL_BASE - (int)r_; } while (0)
@@ -58,6 +58,12 @@ struct mi_spmm_dist {
     std::vector<void *> peer_base;             // what hipIpcOpenMemHandle returned (to close)
     std::vector<float *> peer_C;               // the peers' C_full
     float *exported_C = nullptr;
+    // ipc_pull: the peers' two staging buffers, mapped through HIP IPC
+    std::vector<void *> peer_stage_base;       // [world * 2], to close
+    std::vector<float *> peer_stage;           // [world * 2]: peer q's staging[b] at q * 2 + b
+    // a cross-rank barrier supplied by the host, used where a step needs one and no communicator exists
+    mi_spmm_dist_barrier_fn host_barrier = nullptr;
+    void *host_barrier_ctx = nullptr;
 };
 
 namespace {
@@ -79,8 +85,11 @@ void make_panels(mi_spmm_dist *d)
     }
 }
 
+void close_peer_staging(mi_spmm_dist *d);
+
 void free_staging(mi_spmm_dist *d)
 {
+    close_peer_staging(d);       // the peers' view of OUR buffers dies with them too: ipc_pull needs a new export / set round
     for (int i = 0; i < 2; ++i) {
         if (d->staging[i]) (void)hipFree(d->staging[i]);
         d->staging[i] = nullptr;
@@ -158,6 +167,26 @@ int device_barrier(mi_spmm_dist *d, hipStream_t s)
     return 0;
 }
 
+void close_peer_staging(mi_spmm_dist *d)
+{
+    for (void *b : d->peer_stage_base)
+        if (b) (void)hipIpcCloseMemHandle(b);
+    d->peer_stage_base.clear();
+    d->peer_stage.clear();
+}
+
+// Every rank has reached this point of the step: the communicator's one-element all-reduce on stream s, or -- without a
+// communicator -- the host's barrier after this rank's two streams have drained (rehearsal-grade: it serialises the step).
+int step_barrier(mi_spmm_dist *d, hipStream_t s, hipStream_t also)
+{
+    if (d->comm) return device_barrier(d, s);
+    if (!d->host_barrier) return MI_SPMM_ESTATE;
+    HIP_TRY(hipStreamSynchronize(also));
+    HIP_TRY(hipStreamSynchronize(s));
+    d->host_barrier(d->host_barrier_ctx);
+    return 0;
+}
+
 void close_peers(mi_spmm_dist *d)
 {
     for (void *b : d->peer_base)
@@ -204,6 +233,9 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
         // into C_full buffers that may still be read, and nobody would know when the pushes have landed -- refuse, unless
         // the caller has said that it brackets every step with a cross-rank barrier of its own ("external_barrier")
         if (do_exchange && d->world > 1 && !d->comm && !d->external_barrier) return MI_SPMM_ESTATE;
+    } else if (d->exchange == kIpcPull) {
+        if ((int)d->peer_stage.size() != 2 * d->world) return MI_SPMM_ESTATE;
+        if (d->world > 1 && !d->comm && !d->host_barrier) return MI_SPMM_ESTATE;
     } else if (!d->comm) return MI_SPMM_ESTATE;
     MI_TRY(ensure_streams(d));
     MI_TRY(ensure_panel_events(d));
@@ -280,6 +312,18 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
         HIP_TRY(hipEventRecord(d->ev_computed[p], main));
         if (!do_exchange) continue;
         HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_computed[p], 0));
+        if (d->exchange == kIpcPull) {
+            // every rank's block of this panel sits in its own staging buffer: pull the peers' blocks out of THEIR buffers
+            // (same rank-major layout, same slot) into ours, then tell them we are done with their buffer
+            MI_TRY(step_barrier(d, d->s_comm, main));
+            const size_t blk = (size_t)rows * (size_t)n_loc;
+            for (int k = 1; k < d->world; ++k) {
+                const int from = (d->rank + k) % d->world;
+                HIP_TRY(hipMemcpyAsync(stage + (size_t)from * blk, d->peer_stage[(size_t)from * 2 + (p & 1)] + (size_t)from * blk, blk * sizeof(float),
+                                       hipMemcpyDeviceToDevice, d->s_comm));
+            }
+            MI_TRY(step_barrier(d, d->s_comm, main));
+        } else
         MI_TRY(exchange_panel(d, stage, rows, d->s_comm));
         HIP_TRY(hipEventRecord(d->ev_gathered[p], d->s_comm));
         HIP_TRY(hipStreamWaitEvent(d->s_post, d->ev_gathered[p], 0));
@@ -334,6 +378,7 @@ int mi_spmm_dist_destroy(mi_spmm_dist *d)
     if (!good(d)) return MI_SPMM_ESTATE;
     (void)hipDeviceSynchronize();
     close_peers(d);
+    close_peer_staging(d);
     free_staging(d);
     if (d->d_token) (void)hipFree(d->d_token);
     if (d->comm && d->own_comm) (void)ncclCommDestroy(d->comm);
@@ -415,11 +460,57 @@ int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles
     return 0;
 }
 
+int mi_spmm_dist_set_host_barrier(mi_spmm_dist *d, mi_spmm_dist_barrier_fn fn, void *ctx)
+{
+    if (!good(d)) return MI_SPMM_EINVAL;
+    d->host_barrier = fn;
+    d->host_barrier_ctx = ctx;
+    return 0;
+}
+
+int mi_spmm_dist_export_staging(mi_spmm_dist *d, void *handles_out, int64_t *offsets_out)
+{
+    if (!good(d) || !handles_out || !offsets_out) return MI_SPMM_EINVAL;
+    MI_TRY(ensure_staging(d));
+    for (int b = 0; b < 2; ++b) {
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d->staging[b]));
+        hipIpcMemHandle_t hnd;
+        HIP_TRY(hipIpcGetMemHandle(&hnd, base));
+        std::memcpy((char *)handles_out + (size_t)b * sizeof(hnd), &hnd, sizeof(hnd));
+        offsets_out[b] = (int64_t)((char *)d->staging[b] - (char *)base);
+    }
+    return 0;
+}
+
+int mi_spmm_dist_set_peer_staging(mi_spmm_dist *d, const void *handles, const int64_t *offsets)
+{
+    if (!good(d) || !handles || !offsets) return MI_SPMM_EINVAL;
+    MI_TRY(ensure_staging(d));
+    close_peer_staging(d);
+    d->peer_stage_base.assign((size_t)d->world * 2, nullptr);
+    d->peer_stage.assign((size_t)d->world * 2, nullptr);
+    for (int q = 0; q < d->world; ++q)
+        for (int b = 0; b < 2; ++b) {
+            const size_t i = (size_t)q * 2 + b;
+            if (q == d->rank) { d->peer_stage[i] = d->staging[b]; continue; }
+            hipIpcMemHandle_t hnd;
+            std::memcpy(&hnd, (const char *)handles + i * sizeof(hnd), sizeof(hnd));
+            void *base = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&base, hnd, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { close_peer_staging(d); return (int)e; }
+            d->peer_stage_base[i] = base;
+            d->peer_stage[i] = (float *)((char *)base + offsets[i]);
+        }
+    return 0;
+}
+
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
 {
     if (!good(d) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
-    if (k == "exchange") { if (v < 0 || v > 3) return MI_SPMM_EINVAL; d->exchange = (int)v; }
+    if (k == "exchange") { if (v < 0 || v > 4) return MI_SPMM_EINVAL; d->exchange = (int)v; }
     else if (k == "rehearse") d->rehearse = v != 0;
     else if (k == "external_barrier") d->external_barrier = v != 0;
     else if (k == "n_panels") {

@@ -254,6 +254,9 @@ _DIST_SIGNATURES = {
     "mi_spmm_dist_set_comm": (_C.c_int, [_P, _P]),
     "mi_spmm_dist_export_c": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_set_peers": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_export_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_set_peer_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_set_host_barrier": (_C.c_int, [_P, _P, _P]),
     "mi_spmm_dist_set_option": (_C.c_int, [_P, _C.c_char_p, _C.c_int64]),
     "mi_spmm_dist_get_option": (_C.c_int, [_P, _C.c_char_p, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_run": (_C.c_int, [_P, _P, _P, _P]),
@@ -263,7 +266,8 @@ _DIST_SIGNATURES = {
 }
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
-EXCHANGE_CODES = {"allgather": 0, "direct": 1, "peer2d": 2, "peer_store": 3}
+EXCHANGE_CODES = {"allgather": 0, "direct": 1, "peer2d": 2, "peer_store": 3, "ipc_pull": 4}
+_BARRIER_FN = _C.CFUNCTYPE(None, _C.c_void_p)
 
 
 class MiSpmmDistError(RuntimeError):
@@ -378,6 +382,34 @@ class NativeColumnShardedSpMM:
             offsets[q] = ob
         _dcheck(self._lib.mi_spmm_dist_set_peers(self._d, _P(C_full.data_ptr()), handles, offsets), "mi_spmm_dist_set_peers")
         self._peers_of = C_full           # keep the exported tensor alive
+
+    def set_peer_staging(self):
+        """Collective (exchange="ipc_pull").  Every rank exports its two staging buffers; the table goes to the library."""
+        import torch.distributed as dist
+
+        L = self.layout
+        h = (_C.c_char * (2 * IPC_HANDLE_BYTES))()
+        off = (_C.c_int64 * 2)()
+        _dcheck(self._lib.mi_spmm_dist_export_staging(self._d, h, off), "mi_spmm_dist_export_staging")
+        mine = (bytes(h), [int(off[0]), int(off[1])])
+        if L.world > 1:
+            table = [None] * L.world
+            dist.all_gather_object(table, mine, group=self.group)
+        else:
+            table = [mine]
+        handles = (_C.c_char * (2 * IPC_HANDLE_BYTES * L.world))()
+        offsets = (_C.c_int64 * (2 * L.world))()
+        for q, (hb, ob) in enumerate(table):
+            _C.memmove(_C.addressof(handles) + q * 2 * IPC_HANDLE_BYTES, hb, 2 * IPC_HANDLE_BYTES)
+            offsets[2 * q], offsets[2 * q + 1] = ob
+        _dcheck(self._lib.mi_spmm_dist_set_peer_staging(self._d, handles, offsets), "mi_spmm_dist_set_peer_staging")
+
+    def set_host_barrier(self, fn):
+        """fn(): a cross-rank barrier of the host's (e.g. torch.cuda.synchronize(); dist.barrier()), called by the library
+        where a step needs one and there is no communicator.  None removes it."""
+        self._barrier_cb = _BARRIER_FN(lambda ctx: fn()) if fn is not None else None      # keep the thunk alive
+        _dcheck(self._lib.mi_spmm_dist_set_host_barrier(self._d, _C.cast(self._barrier_cb, _P) if self._barrier_cb else None, None),
+                "mi_spmm_dist_set_host_barrier")
 
     @staticmethod
     def _stream():

@@ -31,6 +31,12 @@
  *                 memory system carries the gather (18.0 GB at C3) plus what the peers store INTO it (3.76 GB) and nothing
  *                 else: the only schedule whose byte budget allows the north star's >= 6x at 8 GPUs.
  *                 One launch set over all rows between two barriers; world <= 8.
+ *   4  ipc_pull   the allgather schedule's staging layout, double buffering and re-layout kernel with a different
+ *                 transport: every rank computes its block into its own staging buffer and PULLS the peers' blocks out of
+ *                 their staging buffers (mapped through HIP IPC: mi_spmm_dist_export_staging / _set_peer_staging) with
+ *                 device-to-device copies; two cross-rank barriers per panel (blocks computed / blocks pulled) -- the
+ *                 communicator's all-reduce, or mi_spmm_dist_set_host_barrier's callback.  Exists so that the staging path
+ *                 of a step runs with several real ranks where RCCL cannot (ranks sharing one GPU); not a fast path.
  * 0 and 1 need a communicator (mi_spmm_dist_comm_init); 2 and 3 need the peers' C_full (mi_spmm_dist_set_peers) and,
  * to be self-synchronising, a communicator too (a one-element all-reduce is the end-of-step barrier).  Without a
  * communicator a peer2d step at world > 1 is refused (MI_SPMM_ESTATE) unless "external_barrier" = 1 says that the caller
@@ -76,7 +82,18 @@ int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm);
 int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out);
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
-/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d, 3 peer_store), "n_panels", "rehearse" (1: run the staging / collective /
+/* ipc_pull: export this rank's two staging buffers (2 x 64-byte handles, 2 offsets), all-gather them on the host side, hand
+ * the tables in (world x 2 handles, world x 2 offsets, rank-major).  Re-do both after "n_panels" changes. */
+int mi_spmm_dist_export_staging(mi_spmm_dist *d, void *handles_out, int64_t *offsets_out);
+int mi_spmm_dist_set_peer_staging(mi_spmm_dist *d, const void *handles, const int64_t *offsets);
+
+/* A cross-rank barrier supplied by the host (MPI_Barrier, a gloo barrier ...).  Used where a step needs every rank at the
+ * same point and there is no communicator: the library drains its streams, then calls fn(ctx).  Serialises the step on
+ * the host: for rehearsals and hosts without RCCL, not for speed.  fn == NULL removes it. */
+typedef void (*mi_spmm_dist_barrier_fn)(void *ctx);
+int mi_spmm_dist_set_host_barrier(mi_spmm_dist *d, mi_spmm_dist_barrier_fn fn, void *ctx);
+
+/* keys: "exchange" (0 allgather, 1 direct, 2 peer2d, 3 peer_store, 4 ipc_pull), "n_panels", "rehearse" (1: run the staging / collective /
  * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path), "external_barrier" (see above); read-only: "world", "rank", "has_comm",
  * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step" */
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);

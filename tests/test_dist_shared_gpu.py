@@ -122,17 +122,35 @@ def _native_worker(rank, world, port, M, n_loc, n_panels, kind, exchange, q):
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
         op.preprocess(B_loc, C_full)
         sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=n_panels, exchange=exchange)
-        sh.set_peers(C_full)
-        assert sh.get_option("has_peers") == 1 and sh.get_option("has_comm") == 0
-        # no communicator: the step's two device-side barriers do not exist, so the library refuses to run it ...
         from hpc_amd.dist import MiSpmmDistError
-        try:
-            sh.run(B_loc, C_full)
-            refused = False
-        except MiSpmmDistError as e:
-            refused = e.code == -3           # MI_SPMM_ESTATE
-        assert refused, "peer2d at world > 1 without a communicator must be refused"
-        sh.set_option("external_barrier", 1)     # ... unless the caller says it brackets every step itself (below)
+
+        def host_barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        if exchange == "ipc_pull":
+            # the allgather schedule's staging / double buffer / re-layout path with real ranks: blocks pulled out of the peers'
+            # staging buffers through HIP IPC, the two barriers of every panel supplied by the host (no RCCL on a shared GPU)
+            sh.set_peer_staging()
+            try:
+                sh.run(B_loc, C_full)
+                refused = False
+            except MiSpmmDistError as e:
+                refused = e.code == -3
+            assert refused, "ipc_pull at world > 1 with neither communicator nor host barrier must be refused"
+            sh.set_host_barrier(host_barrier)
+            assert sh.get_option("has_comm") == 0 and sh.get_option("staging_bytes") > 0
+        else:
+            sh.set_peers(C_full)
+            assert sh.get_option("has_peers") == 1 and sh.get_option("has_comm") == 0
+            # no communicator: the step's two device-side barriers do not exist, so the library refuses to run it ...
+            try:
+                sh.run(B_loc, C_full)
+                refused = False
+            except MiSpmmDistError as e:
+                refused = e.code == -3           # MI_SPMM_ESTATE
+            assert refused, "peer2d at world > 1 without a communicator must be refused"
+            sh.set_option("external_barrier", 1)     # ... unless the caller says it brackets every step itself (below)
 
         def barrier():
             torch.cuda.synchronize()
@@ -157,7 +175,7 @@ def _native_worker(rank, world, port, M, n_loc, n_panels, kind, exchange, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["peer2d", "peer_store"])
+@pytest.mark.parametrize("exchange", ["peer2d", "peer_store", "ipc_pull"])
 @pytest.mark.parametrize("world,M,n_loc,n_panels,kind", [(2, 40000, 128, 8, "uniform"), (3, 30011, 64, 5, "powerlaw")])
 def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n_panels, kind, exchange):
     import torch.multiprocessing as mp
@@ -177,6 +195,6 @@ def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n
                 p.kill()
     assert all(p.exitcode == 0 for p in procs)
     for rank, same, staging, nans in sorted(got):
-        assert staging == 0, "peer2d must not allocate staging"
+        assert (staging == 0) == (exchange != "ipc_pull"), "peer2d / peer_store must not allocate staging; ipc_pull must"
         assert nans == 0, f"rank {rank}: {nans} elements of C never written"
         assert same, f"rank {rank}: C differs from the single-operator C"
