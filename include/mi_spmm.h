@@ -25,9 +25,11 @@
  *     the given stream and performs no host synchronisation;
  *   - arithmetic per output element: fp32 fused multiply-add chain over the
  *     row's nonzeros in stored order starting from +0.0f (spmm_ref.cu:10-14
- *     under the reference's nvcc --use_fast_math build).  Rows handled by the
- *     exact-order kernels are bit-identical to that chain; rows longer than
- *     the split threshold are summed in chunks (tolerance: DESIGN.md).
+ *     under the reference's nvcc --use_fast_math build).  With default options
+ *     EVERY row is that chain, bit for bit, whatever its length (short rows,
+ *     single segments, hub rows through the hub kernel, block groups through
+ *     the f32 MFMA).  Only the opt-in "split_long_rows" = 1 sums rows longer
+ *     than the threshold piece by piece (tolerance: DESIGN.md).
  *
  * Errors: the reference aborts (include/util.h:63-84).  The C ABI never
  * aborts: every function returns 0 on success or a negative MI_SPMM_E* /
@@ -118,9 +120,20 @@ const char *mi_spmm_strerror(int code);
  *   "medium_row_threshold" rows longer than this run as ONE exact segment in the segment kernel (0 = auto:
  *                         64, or 32 when the longest row exceeds 8x the mean degree; get returns the
  *                         resolved value after preprocess).  Scheduling only: results do not depend on it
- *   "long_row_threshold"  rows with more nonzeros are split into chunks (0 = auto:
- *                         clamp(nnz/8192, 256, 2048); get returns the resolved value after preprocess)
- *   "long_row_chunk"      chunk length in nonzeros
+ *   "long_row_threshold"  rows with more nonzeros are HUBS: they leave the segment kernel for the hub kernel (stored order:
+ *                         loader waves + one chain wave per 32-column slice, 6.5 ns per nonzero of a row instead of 47).
+ *                         0 = auto: a power of two in 256 .. 8192 from the row-length histogram (hpc_amd/csrc/plan.hpp
+ *                         resolve_hub_threshold); get returns the resolved value after preprocess.  Scheduling only in
+ *                         the default mode: results do not depend on it
+ *   "split_long_rows"     0 (default): hubs keep their stored order.  1: hubs are cut into pieces of "long_row_chunk"
+ *                         nonzeros whose partial sums are added left to right (deterministic, not the reference's order;
+ *                         auto threshold then clamp(nnz/8192, 256, 2048)).  Faster only when one row holds a few per cent
+ *                         of a small matrix (an exact chain cannot run faster than 5.4 cycles per nonzero of that row)
+ *   "long_row_chunk"      piece length in nonzeros (split mode)
+ *   "hub_slice"           columns per hub workgroup: 16, 32, 64; 0 = auto (32; 16 when N <= 16)
+ *   "hub_overlap"         1 (default): the hub and segment kernels run on handle-owned side streams forked from and joined
+ *                         into the caller's stream inside every run call, when the step is long enough to hide their
+ *                         longest rows behind the rows kernel (the fork costs ~20 us); 0: never; 2: always
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
  *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel (8, 16, 32; default 32)
@@ -130,7 +143,7 @@ const char *mi_spmm_strerror(int code);
  *                         (K x tile_cols x 4 bytes).  Scheduling only: results do not depend on it
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto
  *   "gpu_preprocess"      1 (default): segment table built on the device; 0: reference-style host loop
- *   "kernel"              1: per-row fetch (spmm_rows), 2: pipelined items (spmm_rows_v2, default)
+ *   "kernel"              2: pipelined items (spmm_rows_v2).  1 named the first-generation kernel: MI_SPMM_EUNSUPPORTED
  *   "nt_store"            0/1: non-temporal stores of C
  *   "nt_stream"           0/1: non-temporal loads of col_idx/vals
  *   "block_path"          0/1: 16-row groups sharing one column list go through the MFMA path
@@ -140,11 +153,11 @@ const char *mi_spmm_strerror(int code);
  *   "block_run_min"       shortest run worth a piece (and a pass) of its own; a list with a shorter run stays whole
  *   "block_share"         most pieces that share one fetch of their B rows (1 or 2)
  * set before preprocess; get any time.  Read-only keys after preprocess:
- *   "n_long_rows", "n_chunks", "workspace_bytes", "n_launches", "lanes_per_row", "preprocess_us",
+ *   "n_long_rows" (rows above the threshold), "n_hub_rows" (those of them the hub kernel takes: all, or 0 in split mode),
+ *   "n_medium_rows", "n_chunks", "n_partial_slots", "workspace_bytes" (plan tables + partial sums + preprocess arenas),
+ *   "n_launches", "lanes_per_row", "preprocess_us", "feat", "num_v", "num_cols", "max_row_nnz",
  *   "n_block_groups", "n_block_pieces", "n_block_items", "n_block_shared_items", "n_block_passes",
- *   "column_locality_pct" (share of sampled nonzeros near their row's own position; behind the "tile_cols" auto rule)
- * Not in this library: "kernel" = 1 and "block_ablate" (first-generation / timing-only kernels) answer
- * MI_SPMM_EUNSUPPORTED; they exist only in the A/B build (make -C hpc_amd/csrc ablate). */
+ *   "column_locality_pct" (share of sampled nonzeros near their row's own position; behind the "tile_cols" auto rule) */
 int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t value);
 int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value);
 
