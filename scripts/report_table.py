@@ -99,17 +99,17 @@ def main():
                 t_stud = timed(lambda: ro.run(d_B, d_V), 1, 3)            # accumulates; timing only
                 del ro
             rows_out[N].append((name, M, nnz, int(deg.max()), t_vend, t_ours, t_vend / t_ours, t_stud, t_stud / t_ours, ok,
-                                ours.get_option("n_long_rows")))
+                                ours.get_option("n_hub_rows"), ours.get_option("n_partial_slots"), ours.get_option("long_row_threshold")))
             del d_B, d_C, d_V, ours, vend
         del d_ptr, d_idx, d_val, g
         torch.cuda.empty_cache()
     print("# Reference-style report table on MI355X (dataset-shaped synthetic graphs; see scripts/report_table.py)\n")
     for N in lens:
         print(f"### `kLen = {N}`\n")
-        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | split rows |")
-        print("|---|---|---|---|---|---|---|---|---|---|---|")
+        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|---|")
         for r in rows_out[N]:
-            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {r[10]} |")
+            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} |")
         sp = [r[6] for r in rows_out[N]]
         if sp:
             print(f"\nspeed-up over the vendor library: min {min(sp):.2f}, geometric mean {float(np.exp(np.mean(np.log(sp)))):.2f}, max {max(sp):.2f} "
