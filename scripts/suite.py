@@ -39,7 +39,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ref", action="store_true")
-    ap.add_argument("--ab", action="store_true", help="interleaved A/B of rows kernel v1 vs v2")
     ap.add_argument("--vendor", action="store_true", help="also time rocSPARSE (the reference's headline comparator)")
     ap.add_argument("--M", type=int, default=1 << 20)
     ap.add_argument("--only", default=None)
@@ -84,19 +83,14 @@ def main():
                 op.set_option(k, int(v))
             op.preprocess(d_B, d_C)
             ms = timed(lambda: op.run(d_B, d_C), 3, 10)
-            ab = {}
-            if args.ab:
-                for kern in (1, 2, 1, 2):
-                    op.set_option("kernel", kern)
-                    ab.setdefault(f"kernel{kern}_ms", []).append(round(timed(lambda: op.run(d_B, d_C), 2, 10), 4))
-                op.set_option("kernel", 2)
             model = synth.bytes_model(M, M, N, nnz)
             row = {"structure": sname, "M": M, "nnz": nnz, "deg_mean": round(float(deg.mean()), 2), "deg_max": int(deg.max()), "N": N,
                    "ours_ms": round(ms, 4), "ours_gflops": round(model["flops"] / ms / 1e6, 1),
                    "ours_GBs_alg": round(model["bytes_alg"] / ms / 1e6, 1), "frac_8TBs": round(model["bytes_alg"] / ms / 1e6 / 8000, 4),
                    "GBs_min_model": round(model["bytes_min"] / ms / 1e6, 1),
-                   "n_long_rows": op.get_option("n_long_rows"), "n_chunks": op.get_option("n_chunks"),
-                   "ab": ab, "lanes_per_row": op.get_option("lanes_per_row"), "preprocess_us": op.get_option("preprocess_us"), "gen_s": round(gen_s, 1)}
+                   "n_hub_rows": op.get_option("n_hub_rows"), "hub_threshold": op.get_option("long_row_threshold"), "n_segments": op.get_option("n_chunks"),
+                   "rows_out_of_stored_order": op.get_option("n_long_rows") if op.get_option("split_long_rows") else 0,
+                   "lanes_per_row": op.get_option("lanes_per_row"), "preprocess_us": op.get_option("preprocess_us"), "gen_s": round(gen_s, 1)}
             if args.vendor:
                 from hpc_amd.comparator import SpMMRocSparse
                 from hpc_amd import valid as _valid
