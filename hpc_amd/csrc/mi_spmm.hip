@@ -73,6 +73,7 @@ struct mi_spmm_handle {
     // block path, run time: pieces of the groups' column lists, grouped into items, per pass (spmm_kernels.hpp)
     int64_t block_share;       // most pieces per item (1 = no sharing; default 2)
     int64_t block_max_pieces;  // most pieces a group's list is cut into = most passes (1 = never cut)
+    int64_t block_wg_waves;    // waves (= items) per workgroup of the block kernels: 1 (default), 2, 4
     int64_t block_run_min;     // shortest run worth a piece of its own
     BlockItem *d_blk_items;    // grow-only (capacity blk_items_cap items): kept across preprocess calls, released by destroy
     size_t blk_items_cap;
@@ -461,6 +462,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->block_share = 2;
     h->block_max_pieces = kMaxPieces;
     h->block_run_min = 32;
+    h->block_wg_waves = 1;
     h->kernel = 2;
     h->gpu_preprocess = 1;
     h->block_threads = 256;
@@ -527,6 +529,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "block_min_len") { if (v < 1) return MI_SPMM_EINVAL; h->block_min_len = v; free_plan(h); }
     else if (k == "block_share") { if (v < 1 || v > kMaxShare) return MI_SPMM_EINVAL; h->block_share = v; free_plan(h); }
     else if (k == "block_max_pieces") { if (v < 1 || v > kMaxPieces) return MI_SPMM_EINVAL; h->block_max_pieces = v; free_plan(h); }
+    else if (k == "block_wg_waves") { if (v != 1 && v != 2 && v != 4) return MI_SPMM_EINVAL; h->block_wg_waves = v; }
     else if (k == "block_run_min") { if (v < 1) return MI_SPMM_EINVAL; h->block_run_min = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
@@ -573,6 +576,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "block_share") *value = h->block_share;
     else if (k == "block_max_pieces") *value = h->block_max_pieces;
     else if (k == "block_run_min") *value = h->block_run_min;
+    else if (k == "block_wg_waves") *value = h->block_wg_waves;
     else if (k == "n_block_items") *value = h->n_blk_items;
     else if (k == "n_block_pieces") *value = h->n_blk_pieces;
     else if (k == "n_block_passes") *value = h->n_blk_passes;
@@ -875,21 +879,21 @@ void launch_chunks_lpr(int lpr, const ChunkArgs &a, dim3 grid, hipStream_t s, in
 }
 
 template <int G, bool WIDE, bool RUN>
-void launch_block_items_g(int slab, const BlockArgs &a, dim3 grid, hipStream_t s)
+void launch_block_items_g(int slab, const BlockArgs &a, dim3 grid, hipStream_t s, int bt)
 {
     // slab = columns one wave covers: 256 / 128 / 64 as 4 / 2 / 1 chunks of 64 (16 bytes per lane), 32 as one chunk of
     // 32 (8 bytes per lane).  Shared items (G > 1) exist only for 256 and 128 (N % 128 == 0).
-    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<4, 4, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<2, 4, G, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<1, 4, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
-    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<1, 2, 1, WIDE, RUN>), grid, dim3(kBlockThreads), 0, s, a);
+    if (slab == 256) hipLaunchKernelGGL((spmm_block_items<4, 4, G, WIDE, RUN>), grid, dim3(bt), 0, s, a);
+    else if (slab == 128) hipLaunchKernelGGL((spmm_block_items<2, 4, G, WIDE, RUN>), grid, dim3(bt), 0, s, a);
+    else if (G == 1 && slab == 64) hipLaunchKernelGGL((spmm_block_items<1, 4, 1, WIDE, RUN>), grid, dim3(bt), 0, s, a);
+    else if (G == 1) hipLaunchKernelGGL((spmm_block_items<1, 2, 1, WIDE, RUN>), grid, dim3(bt), 0, s, a);
 }
 // cls: 0 = list items, 1 = run items holding one piece, 2 = run items sharing their B rows between two pieces
-void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s)
+void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 grid, hipStream_t s, int bt)
 {
-    if (cls == 2) { if (wide) launch_block_items_g<2, true, true>(slab, a, grid, s); else launch_block_items_g<2, false, true>(slab, a, grid, s); }
-    else if (cls == 1) { if (wide) launch_block_items_g<1, true, true>(slab, a, grid, s); else launch_block_items_g<1, false, true>(slab, a, grid, s); }
-    else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s); else launch_block_items_g<1, false, false>(slab, a, grid, s); }
+    if (cls == 2) { if (wide) launch_block_items_g<2, true, true>(slab, a, grid, s, bt); else launch_block_items_g<2, false, true>(slab, a, grid, s, bt); }
+    else if (cls == 1) { if (wide) launch_block_items_g<1, true, true>(slab, a, grid, s, bt); else launch_block_items_g<1, false, true>(slab, a, grid, s, bt); }
+    else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s, bt); else launch_block_items_g<1, false, false>(slab, a, grid, s, bt); }
 }
 
 template <bool WIDE>
@@ -1073,8 +1077,12 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
                 ba.items = h->d_blk_items + h->blk_launch[pass][cls].off;
                 if (n == 0) continue;
                 ba.n_items = n;
-                dim3 bgrid((unsigned)((n + 3) / 4), slabs);
-                launch_block_items(slab, cls, wide_full, ba, bgrid, s);
+                // one item per wave, and ONE wave per workgroup by default: items differ 4x in length (64 or 128 rows, one or two
+                // pieces), and a 4-wave workgroup holds its four wave slots until its longest item is done -- 1.38 of 2 possible
+                // waves per SIMD were resident against 1.80 with single-wave workgroups (profiles/r03_c4_item_timeline.txt)
+                const int wpw = (int)h->block_wg_waves;
+                dim3 bgrid((unsigned)((n + wpw - 1) / wpw), slabs);
+                launch_block_items(slab, cls, wide_full, ba, bgrid, s, 64 * wpw);
                 ++launches;
             }
         }

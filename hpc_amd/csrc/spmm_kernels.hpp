@@ -766,7 +766,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vblk = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int ii = vblk * 4 + wave;
+    const int ii = vblk * (int)(blockDim.x >> 6) + wave;   // one item per wave; the workgroup is 1..4 waves ("block_wg_waves")
     if (ii >= a.n_items) return;          // wave-uniform (the kernel has no workgroup barrier)
     const int i16 = lane & 15, kq = lane >> 4;
     const int slab0 = (int)blockIdx.y * NS;
