@@ -1089,7 +1089,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     }
 
     RowsArgs a;
-    a.blk_flag = blocks_on ? h->d_blk_flag : nullptr;
+    a.blk_flag = h->n_blk_groups > 0 ? h->d_blk_flag : nullptr;
     a.row_ptr = h->d_ptr;
     a.col_idx = h->d_idx;
     a.vals = h->d_val;
@@ -1101,13 +1101,13 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     a.M = row_end;
     a.N = N;
     a.rows_per_block = rpg;
-    // rows above the medium threshold were given to the segment kernel -- except rows of block groups
-    // when the block path cannot run here (pointers or pitches not 16-byte aligned): then the rows kernel takes every
-    // unsplit row again (medium rows are computed twice with identical bits; stream order keeps it benign)
+    // rows above the medium threshold were given to the segment or hub kernel -- except rows of block groups (of any
+    // length up to the detection cap): when the block path cannot run on this call (pointers or pitches not 16-byte
+    // aligned) the rows kernel takes exactly those rows as well (kFlagBlockFallback), nothing is computed twice
     const bool blocks_fallback = h->n_blk_groups > 0 && !blocks_on;
-    a.long_thr = (int32_t)(blocks_fallback ? h->long_thr : h->medium_res);
+    a.long_thr = (int32_t)h->medium_res;
     a.nblk = (int)nblk64;
-    a.flags = flags;
+    a.flags = flags | (blocks_fallback ? kFlagBlockFallback : 0);
     a.po = po;
     dim3 grid((unsigned)nblk64, col_tiles);
     // every row may already be owned by the segment, split and block paths: nothing left to launch

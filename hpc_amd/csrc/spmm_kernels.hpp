@@ -49,7 +49,7 @@ struct RowsArgs {
     PeerOut po;
 };
 
-enum : int32_t { kFlagXcdRemap = 4 };
+enum : int32_t { kFlagXcdRemap = 4, kFlagBlockFallback = 8 };   // fallback: the block kernels cannot run on this call (alignment): the rows kernel takes the block groups' rows, whatever their length
 
 // Blocks b and b+8 land on the same XCD (round-robin dispatch; speed only,
 // never correctness -- cdna_hip_programming.md T1).  Give each XCD one
@@ -285,9 +285,10 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
     // LPR - 1 rows can span five 16-row groups, each owned (or not) by the MFMA path independently
     int myflag = 0;
     if (a.blk_flag) myflag = a.blk_flag[(gbase + min(lig, nrows - 1)) >> 4];
+    const bool blk_fallback = (a.flags & kFlagBlockFallback) != 0;
     auto mine = [&](int ri, int rbeg, int rend) -> bool {
         const int f = a.blk_flag ? group_bcast<LPR>(myflag, ri) : 0;
-        return (rend - rbeg <= a.long_thr) && f == 0;
+        return f ? blk_fallback : (rend - rbeg <= a.long_thr);
     };
 
     int ri = 0;

@@ -143,3 +143,18 @@ def test_dist_argument_checks_without_a_gpu():
     assert b"NCCL" in lib.mi_spmm_dist_strerror(-1003) or b"internal" in lib.mi_spmm_dist_strerror(-1003)
     assert b"invalid argument" in lib.mi_spmm_dist_strerror(-1)
     _lib.load().mi_spmm_destroy(h)
+
+
+def test_profiles_text_files_are_sane():
+    """Evidence files under profiles/ are small and not a paragraph repeated thousands of times (round 2 lost one that way:
+    an append script iterated over the characters of the old text)."""
+    import collections
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "profiles", "*.txt")) + glob.glob(os.path.join(root, "profiles", "*.md")):
+        assert os.path.getsize(path) < 400_000, f"{path}: {os.path.getsize(path)} bytes"
+        lines = [l.strip() for l in open(path, errors="replace") if len(l.strip()) > 40]
+        if lines:
+            line, n = collections.Counter(lines).most_common(1)[0]
+            assert n <= 20, f"{path}: a line repeated {n} times: {line[:60]!r}"

@@ -1051,6 +1051,32 @@ def test_unaligned_pointers_fall_back_cleanly(device, oracle):
     got = Cbuf[1:].view(M, 128).cpu().numpy()
     assert np.array_equal(bits(got), bits(oracle.spmm_omp(ptr, idx, vals, B)))
     assert torch.isnan(Cbuf[0])
+    # auto hub threshold (256 here) BELOW a block group's list length (1100): the group still belongs to the block path
+    # (detection goes up to the auto rule's largest candidate), and on an unaligned call the rows kernel must take its rows
+    # although they are longer than every threshold.  20 000 short rows keep the group's share of the nonzeros small.
+    g = np.random.Generator(np.random.Philox(key=[6, 6]))
+    cols = np.sort(g.choice(1200, 1100, replace=False)).astype(np.int32)
+    bp, bi = synth.csr_uniform(20000, 10, 30, K=1200, seed=77)
+    pad = (-(ptr.size - 1 + 20000)) % 16             # empty rows so that the appended group starts on a 16-row boundary
+    ptr2 = np.concatenate([ptr, ptr[-1] + bp[1:], np.full(pad, ptr[-1] + bp[-1]), ptr[-1] + bp[-1] + 1100 * np.arange(1, 17)]).astype(np.int32)
+    idx2 = np.concatenate([idx, bi] + [cols] * 16).astype(np.int32)
+    assert (ptr2.size - 1) % 16 == 0 and ptr2[-1] == idx2.size
+    vals2 = synth.normal_f32(idx2.size, 3)
+    M2 = ptr2.size - 1
+    d_ptr2, d_idx2, d_val2 = to_dev(device, ptr2, idx2, vals2)
+    Cbuf2 = torch.full((M2 * 128 + 1,), float("nan"), device=device)
+    op2 = SpMMOpt(CSR(M2, idx2.size, d_ptr2, d_idx2, d_val2), 128, num_cols=1200)
+    op2.preprocess(Bbuf[1:], Cbuf2[1:])
+    assert op2.get_option("long_row_threshold") == 256 and op2.get_option("n_block_groups") > 0
+    exp2 = oracle.spmm_omp(ptr2, idx2, vals2, B)
+    op2.run(Bbuf[1:], Cbuf2[1:])                     # unaligned: fallback
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(Cbuf2[1:].view(M2, 128).cpu().numpy()), bits(exp2))
+    d_B2 = torch.from_numpy(B).to(device)
+    d_C2 = torch.full((M2, 128), float("nan"), device=device)
+    op2.run(d_B2, d_C2)                              # aligned: the MFMA path takes the 500-long group
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C2.cpu().numpy()), bits(exp2))
 
 
 def test_wide_addressing_variants(device, oracle):
