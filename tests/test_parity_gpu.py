@@ -152,6 +152,28 @@ def test_split_rows_chunk_order_and_tolerance(device, oracle, thr, chunk, N):
     assert np.array_equal(bits(C0), bits(plain)), "the default path must keep the stored order on every row"
 
 
+@pytest.mark.parametrize("N", [4, 5, 31, 32, 33, 64, 100, 128, 260])
+def test_hub_kernel_stage_and_ring_boundaries(device, oracle, N):
+    """Hub rows whose lengths sit on and around the hub kernel's internal boundaries -- the 64-nonzero stage (63 / 64 / 65), the
+    half stage (31 / 33), the three loaders' round (191 / 192 / 193), the six-slot ring wrapping (383 / 384 / 385, 449), many
+    trips (1 000, 5 000) -- for every slice width, with unsorted and repeated columns, next to short and medium rows:
+    always the plain oracle's bits."""
+    lens = [63, 64, 65, 31, 33, 127, 128, 129, 191, 192, 193, 383, 384, 385, 449, 1000, 5000, 40, 3, 0, 70, 256, 257]
+    K = 3000
+    g = np.random.Generator(np.random.Philox(key=[515, N]))
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = g.integers(0, K, size=int(ptr[-1])).astype(np.int32)          # unsorted, with repeats
+    vals = synth.normal_f32(idx.size, 516)
+    B = synth.normal_f32(K * N, 517).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    for opts in ({"hub_slice": 0}, {"hub_slice": 16}, {"hub_slice": 32}, {"hub_slice": 64}, {"hub_overlap": 2}):
+        o = {"long_row_threshold": 30, "medium_row_threshold": 8}
+        o.update(opts)
+        C, op = run_spmm(device, ptr, idx, vals, B, options=o, num_cols=K)
+        assert op.get_option("n_hub_rows") == sum(1 for x in lens if x > 30) and op.get_option("n_partial_slots") == 0
+        assert np.array_equal(bits(C), bits(exp)), (opts, [lens[i] for i in np.nonzero((bits(C) != bits(exp)).any(axis=1))[0]])
+
+
 def test_power_law_rows(device, oracle):
     ptr, idx = synth.csr_powerlaw(20000, 32.0, 4096, seed=5)
     vals = synth.normal_f32(idx.size, 6)
