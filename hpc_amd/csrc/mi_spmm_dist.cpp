@@ -506,6 +506,21 @@ int mi_spmm_dist_set_peer_staging(mi_spmm_dist *d, const void *handles, const in
     return 0;
 }
 
+int mi_spmm_dist_set_peer_pointers(mi_spmm_dist *d, float *d_C_full, float *const *peer_C_full)
+{
+    if (!good(d) || !d_C_full || !peer_C_full) return MI_SPMM_EINVAL;
+    close_peers(d);
+    d->peer_base.assign((size_t)d->world, nullptr);          // nothing of ours to close: the pointers are the caller's
+    d->peer_C.assign((size_t)d->world, nullptr);
+    for (int q = 0; q < d->world; ++q) {
+        float *p = q == d->rank ? d_C_full : peer_C_full[q];
+        if (!p) { close_peers(d); return MI_SPMM_EINVAL; }
+        d->peer_C[(size_t)q] = p;
+    }
+    d->exported_C = d_C_full;
+    return 0;
+}
+
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
 {
     if (!good(d) || !key) return MI_SPMM_EINVAL;

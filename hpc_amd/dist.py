@@ -254,6 +254,7 @@ _DIST_SIGNATURES = {
     "mi_spmm_dist_set_comm": (_C.c_int, [_P, _P]),
     "mi_spmm_dist_export_c": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_set_peers": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_set_peer_pointers": (_C.c_int, [_P, _P, _P]),
     "mi_spmm_dist_export_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_set_peer_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_set_host_barrier": (_C.c_int, [_P, _P, _P]),
@@ -382,6 +383,12 @@ class NativeColumnShardedSpMM:
             offsets[q] = ob
         _dcheck(self._lib.mi_spmm_dist_set_peers(self._d, _P(C_full.data_ptr()), handles, offsets), "mi_spmm_dist_set_peers")
         self._peers_of = C_full           # keep the exported tensor alive
+
+    def set_peer_tensors(self, C_full, all_C_full):
+        """exchange "peer2d" / "peer_store" with every rank in THIS process: all_C_full[q] is rank q's C_full tensor."""
+        ptrs = (_P * self.layout.world)(*[_P(t.data_ptr()) for t in all_C_full])
+        _dcheck(self._lib.mi_spmm_dist_set_peer_pointers(self._d, _P(C_full.data_ptr()), ptrs), "mi_spmm_dist_set_peer_pointers")
+        self._peers_of = list(all_C_full)
 
     def set_peer_staging(self):
         """Collective (exchange="ipc_pull").  Every rank exports its two staging buffers; the table goes to the library."""

@@ -82,6 +82,10 @@ int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm);
 int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out);
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
+/* The same table for a host that drives several ranks from ONE process (one thread or object per GPU, peer access enabled by
+ * the host): the peers' C_full as plain device pointers, no IPC.  peer_C_full: world pointers, the rank's own entry ignored. */
+int mi_spmm_dist_set_peer_pointers(mi_spmm_dist *d, float *d_C_full, float *const *peer_C_full);
+
 /* ipc_pull: export this rank's two staging buffers (2 x 64-byte handles, 2 offsets), all-gather them on the host side, hand
  * the tables in (world x 2 handles, world x 2 offsets, rank-major).  Re-do both after "n_panels" changes. */
 int mi_spmm_dist_export_staging(mi_spmm_dist *d, void *handles_out, int64_t *offsets_out);

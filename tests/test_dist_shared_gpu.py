@@ -7,9 +7,12 @@ every rank ends with the row-major C a single operator with N_total columns prod
 bit, on repeated steps (staging reuse across steps and panels)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -198,3 +201,23 @@ def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n
         assert (staging == 0) == (exchange != "ipc_pull"), "peer2d / peer_store must not allocate staging; ipc_pull must"
         assert nans == 0, f"rank {rank}: {nans} elements of C never written"
         assert same, f"rank {rank}: C differs from the single-operator C"
+
+
+@pytest.mark.parametrize("exchange", ["peer2d", "peer_store"])
+@pytest.mark.parametrize("world,kind", [(2, "uniform"), (4, "powerlaw")])
+def test_ranks_in_one_process_through_peer_pointers(exchange, world, kind):
+    """mi_spmm_dist_set_peer_pointers: a host that drives every rank from one process hands the peers' C_full in as plain device
+    pointers (no IPC).  Four rank objects on the one GPU, hub rows included: every C_full equals the single-operator C bit for bit."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dist_inprocess
+
+    dev = torch.device("cuda:0")
+    shs, B, C, C_one, keep, nnz = dist_inprocess.build(world, 20011, 64, exchange, dev, kind=kind)
+    for _ in range(2):
+        dist_inprocess.step(shs, B, C)
+    torch.cuda.synchronize()
+    for r, c in enumerate(C):
+        assert not torch.isnan(c).any(), r
+        assert torch.equal(c.view(torch.int32), C_one.view(torch.int32)), r
