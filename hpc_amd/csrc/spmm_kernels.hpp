@@ -437,6 +437,7 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
 //     (chain wave -> loaders, so a slot is not overwritten early).  A wave's LDS operations execute in order, so a
 //     flag written after the data is seen after the data; no barrier inside the loop, one at kernel start.
 // Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, the loaders' writes 2-way.
+#include "hub_chain_asm.inc"
 struct HubArgs {
     const LongRow *rows;     // hub rows, longest first
     const int32_t *row_ptr;
@@ -508,67 +509,29 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
         const int cj = lane % SW;
         const int n_full = len / K::ST;          // whole stages; a last partial one is walked element by element
         float acc = 0.f;
-        constexpr int HQ = K::ST / 8;             // 16-byte quads per half stage
-        typedef float4v Set[HQ];
-        Set b0, a0, b1, a1;                       // set 0: first half of a stage, set 1: second half
-        // Stage t is loader t % L's stage number t / L.  The loaders run ahead (they wait for slots, not we for stages), so
-        // the count read for one stage usually covers the next ones too: it is kept in a scalar register and LDS is
-        // polled only when it runs out (a poll is a full LDS round trip on the chain: ~190 cycles per stage when done every time).
-        int seen[L];
-#pragma unroll
-        for (int w2 = 0; w2 < L; ++w2) seen[w2] = 0;
-        auto wait_ready = [&](int t) {
-            const int w2 = t % L, need = t / L + 1;
-#pragma unroll
-            for (int x = 0; x < L; ++x) {
-                if (x == w2 && seen[x] < need) {
-                    int v;
-                    while ((v = hub_flag_load(&flags[x])) < need) __builtin_amdgcn_s_sleep(1);
-                    seen[x] = v;
-                }
-            }
-            asm volatile("" ::: "memory");
-        };
-        // the chain over the half stage held in (cb, ca), with the reads of half `half` of stage tn into (nb, na) between its links
-        auto trip = [&](const Set &cb, const Set &ca, Set &nb, Set &na, int tn, int half, bool fetch) {
-            const float *bs = &ring[(tn % NB) * K::SLOT_FLOATS + cj * CS + 4 * HQ * half];
-            const float *vs = &ring[(tn % NB) * K::SLOT_FLOATS + SW * CS + 4 * HQ * half];
-            if (fetch) {
-#pragma unroll
-                for (int i = 0; i < HQ; ++i) {
-                    nb[i] = *reinterpret_cast<const float4v *>(bs + 4 * i);
-                    na[i] = *reinterpret_cast<const float4v *>(vs + 4 * i);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(cb[i][e], ca[i][e], acc);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two LDS reads ...
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // ... then four links of the chain
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < HQ; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(cb[i][e], ca[i][e], acc);
-            }
+        auto spin_ready = [&](int w2, int need) {            // stage t is loader t % L's stage number t / L
+            while (hub_flag_load(&flags[w2]) < need) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         };
         if (n_full > 0) {
-            wait_ready(0);
-            const float *bs = &ring[cj * CS], *vs = &ring[SW * CS];
-#pragma unroll
-            for (int i = 0; i < HQ; ++i) {
-                b0[i] = *reinterpret_cast<const float4v *>(bs + 4 * i);
-                a0[i] = *reinterpret_cast<const float4v *>(vs + 4 * i);
-            }
-        }
-        for (int t = 0; t < n_full; ++t) {
-            trip(b0, a0, b1, a1, t, 1, true);                 // first half of stage t; its second half arrives
-            hub_flag_store(&flags[L], t + 1);                 // stage t is in registers: its slot may be refilled
-            const bool more = t + 1 < n_full;
-            if (more) wait_ready(t + 1);
-            trip(b1, a1, b0, a0, t + 1, 0, more);             // second half; the next stage's first half arrives
+            // The whole stages, in assembly (gen_hub_chain.py -> hub_chain_asm.inc, where the why is written down).  Per stage
+            // of 64 nonzeros and two half-stage register sets: [the 16 reads of the next half stage, back to back]
+            // [32 v_fmac_f32, k ascending] [s_waitcnt lgkmcnt(0): the reads are 32 links old] -- twice; the next stage's
+            // published count rides in front of the first group as a 17th read and is looked at a trip later, the `done`
+            // word is written right behind the reads of the stage's second half.  Unrolled over the ring's six slots: every
+            // address is a base register plus an immediate.
+            spin_ready(0, 1);
+            const uint32_t bb = (uint32_t)(size_t)&ring[cj * CS], rba = (uint32_t)(size_t)&ring[SW * CS];
+            const uint32_t fl = (uint32_t)(size_t)&flags[0];
+            static_assert(L == 3 && NB == 6 && K::ST == 64 && CS == 68, "hub_chain_asm.inc is generated for this ring: re-run gen_hub_chain.py");
+#define MI_HUB_CHAIN(TEXT) asm volatile(TEXT : [acc] "+v"(acc) : [bb] "v"(bb), [rba] "s"(rba), [fl] "s"(fl), [nf] "s"(n_full) : MI_HUB_CHAIN_CLOBBERS)
+            if constexpr (SW == 16) MI_HUB_CHAIN(MI_HUB_CHAIN_ASM_16);
+            else if constexpr (SW == 32) MI_HUB_CHAIN(MI_HUB_CHAIN_ASM_32);
+            else MI_HUB_CHAIN(MI_HUB_CHAIN_ASM_64);
+#undef MI_HUB_CHAIN
         }
         if (n_full < n_st) {                      // the partial last stage
-            wait_ready(n_full);
+            spin_ready(n_full % L, n_full / L + 1);
             const float *bs = &ring[(n_full % NB) * K::SLOT_FLOATS + cj * CS];
             const float *vs = &ring[(n_full % NB) * K::SLOT_FLOATS + SW * CS];
             for (int i = 0; i < len - K::ST * n_full; ++i) acc = __builtin_fmaf(bs[i], vs[i], acc);
