@@ -545,7 +545,15 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 
     // ---- loaders: wave w takes stages w, w + L, w + 2L, ...
     const int w = wave - 1;
-    const int part = lane % LPS, g = lane / LPS;
+    // Lane -> (16-byte part of the row slice, nonzero group).  In publish() a lane's write for (e, h) starts at 16-byte
+    // granule (4 part + e) (CS / 4) + g + NG h = 4 part + g + const (mod 16: CS / 4 = 17), and the LDS serves a 16-byte
+    // write 16 lanes at a time: the 16 lanes of a quarter wave must differ in 4 part + g (mod 16).  So a quarter wave is
+    // four parts x four groups (part = lane & 3, g = (lane >> 2) & 3) and the lane's upper bits select further parts
+    // first, then further groups.  (part = lane % LPS, g = lane / LPS: conflict-free at SW = 16 only, 2-way at 32,
+    // 4-way at 64 -- and every conflicting write delays the chain wave's reads.)  Four consecutive lanes still fetch 64
+    // contiguous bytes of one B row.
+    constexpr int PH = LPS / 4;                                  // parts beyond the first four, in lane bits 4..
+    const int part = (lane & 3) + 4 * ((lane >> 4) % PH), g = ((lane >> 2) & 3) + 4 * ((lane >> 4) / PH);
     // A slice that sticks out past N (or a width that is no multiple of 4) shifts its last parts back to column N - 4: they
     // re-fetch and recompute columns of their neighbours with identical bits (as in the rows kernel).
     const int colf = min(slice * SW + 4 * part, a.N - 4);
