@@ -436,7 +436,8 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
 //   * hand-off through two kinds of LDS words: published[w] = stages loader w has written (loader -> chain wave) and done = stages consumed
 //     (chain wave -> loaders, so a slot is not overwritten early).  A wave's LDS operations execute in order, so a
 //     flag written after the data is seen after the data; no barrier inside the loop, one at kernel start.
-// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, the loaders' writes 2-way.
+// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, and so are the loaders'
+// writes with the lane -> (part, group) mapping below.
 #include "hub_chain_asm.inc"
 struct HubArgs {
     const LongRow *rows;     // hub rows, longest first
@@ -501,11 +502,10 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 
     if (wave == 0) {
         // ---- the chain: lane j (mod SW) owns column j of the slice.
-        // One wave alone issues a vector instruction every ~6 cycles and a dependent v_fmac every ~5.4
-        // (scripts/experiments/fma_chain_micro.hip): the chain IS the wave's time, so nothing else may sit on it.  The
-        // 32 LDS reads of a stage cost ~12 cycles each when they are issued in front of the chain; issued one or two per
-        // four fmas, a stage AHEAD (two register sets, the loop unrolled by two so that no register is ever copied), they
-        // hide behind it: 9.4 cycles per nonzero instead of 14.8 (chain_lds_micro.hip).
+        // One wave alone issues an instruction every 5-6 cycles, whatever it is, and a dependent v_fmac every 4.7-5.4
+        // (scripts/experiments/fma_chain_micro.hip, chain_patterns.hip): the chain IS the wave's time, and every other
+        // instruction of the loop is paid in full.  The 32 LDS reads of a stage are fetched half a stage AHEAD into a
+        // second register set, 16 at a time in front of 32 links (the cheapest placement measured).
         const int cj = lane % SW;
         const int n_full = len / K::ST;          // whole stages; a last partial one is walked element by element
         float acc = 0.f;
