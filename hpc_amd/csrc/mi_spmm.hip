@@ -1004,7 +1004,16 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ha.row_lo = row_begin;
         ha.row_hi = row_end;
         ha.po = po_full;
-        const int sw = h->hub_slice > 0 ? (int)h->hub_slice : (full.N <= 16 ? 16 : 32);
+        // Slice width, when the caller leaves it to us: 32 columns per chain wave -- unless the longest row's chain alone
+        // (4.1 ns per nonzero) is more than half of what the whole step's bytes take at 6 TB/s, i.e. that one chain is the
+        // step: then 16, whose loaders put half as much through the LDS the chain wave reads from (am-shaped, N = 128:
+        // 0.84 -> 0.72 ms; where the hub rows are many rather than one long, 32 is faster: R-MAT N = 32 0.47 vs 0.56;
+        // profiles/r03_hub_experiments.txt)
+        int sw = (int)h->hub_slice;
+        if (sw <= 0) {
+            const double step_s = ((double)h->nnz * (4.0 * full.N + 8.0) + 4.0 * (double)h->num_v * full.N) / 6e12;
+            sw = (full.N <= 16 || (double)h->max_row_nnz * 4.1e-9 > 0.5 * step_s) ? 16 : 32;
+        }
         const bool wide_hub = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
                                 ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
         const int slices = (full.N + sw - 1) / sw;

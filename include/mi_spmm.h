@@ -130,7 +130,8 @@ const char *mi_spmm_strerror(int code);
  *                         auto threshold then clamp(nnz/8192, 256, 2048)).  Faster only when one row holds a few per cent
  *                         of a small matrix (an exact chain cannot run faster than 5.4 cycles per nonzero of that row)
  *   "long_row_chunk"      piece length in nonzeros (split mode)
- *   "hub_slice"           columns per hub workgroup: 16, 32, 64; 0 = auto (32; 16 when N <= 16)
+ *   "hub_slice"           columns per hub workgroup: 16, 32, 64; 0 = auto (32; 16 when N <= 16 or when the longest
+ *                         row's chain alone is more than half of the step)
  *   "hub_overlap"         1 (default): the hub and segment kernels run on handle-owned side streams forked from and joined
  *                         into the caller's stream inside every run call, when the step is long enough to hide their
  *                         longest rows behind the rows kernel (the fork costs ~20 us); 0: never; 2: always
