@@ -98,15 +98,20 @@ def text(sw):
     return L
 
 
-clob = [f"v{i}" for i in range(32, 167)] + ["s80", "s81", "s84", "s85", "s86", "scc", "memory"]
-here = os.path.dirname(os.path.abspath(__file__))
-with open(os.path.join(here, "hub_chain_asm.inc"), "w") as f:
-    f.write("// GENERATED by gen_hub_chain.py -- do not edit; see that file for the register map and the protocol.\n")
+def render():
+    clob = [f"v{i}" for i in range(32, 167)] + ["s80", "s81", "s84", "s85", "s86", "scc", "memory"]
+    out = ["// GENERATED by gen_hub_chain.py -- do not edit; see that file for the register map and the protocol.\n"]
     for sw in (16, 32, 64):
-        L = text(sw)
-        f.write(f"#define MI_HUB_CHAIN_ASM_{sw} \\\n")
-        for line in L:
-            f.write(f'    "{line}\\n\\t" \\\n')
-        f.write('    ""\n')
-        print(f"SW = {sw}: {len(L)} lines of assembly, slot {slot_bytes(sw)} bytes")
-    f.write("#define MI_HUB_CHAIN_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
+        out.append(f"#define MI_HUB_CHAIN_ASM_{sw} \\\n")
+        out += [f'    "{line}\\n\\t" \\\n' for line in text(sw)]
+        out.append('    ""\n')
+    out.append("#define MI_HUB_CHAIN_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
+    return "".join(out)
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "hub_chain_asm.inc"), "w") as f:
+        f.write(render())
+    for sw in (16, 32, 64):
+        print(f"SW = {sw}: {len(text(sw))} lines of assembly, slot {slot_bytes(sw)} bytes")

@@ -158,3 +158,21 @@ def test_profiles_text_files_are_sane():
         if lines:
             line, n = collections.Counter(lines).most_common(1)[0]
             assert n <= 20, f"{path}: a line repeated {n} times: {line[:60]!r}"
+
+
+def test_generated_hub_chain_assembly_is_in_sync_with_its_generator():
+    """hpc_amd/csrc/hub_chain_asm.inc (the hub kernel's chain loop) is committed generator output: an edit to either side
+    without the other would ship an assembly loop nobody reviewed."""
+    import importlib.util
+
+    path = os.path.join(ROOT, "hpc_amd", "csrc", "gen_hub_chain.py")
+    spec = importlib.util.spec_from_file_location("gen_hub_chain", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(ROOT, "hpc_amd", "csrc", "hub_chain_asm.inc")) as f:
+        assert f.read() == mod.render()
+    # the ring the text was generated for is the ring the kernel declares (HubCfg in spmm_kernels.hpp)
+    src = open(os.path.join(ROOT, "hpc_amd", "csrc", "spmm_kernels.hpp")).read()
+    for decl in ("static constexpr int ST = 64;", "static constexpr int L = 3;", "static constexpr int CS = ST + 4;", "static constexpr int NB = 2 * L;"):
+        assert decl in src, decl
+    assert (mod.ST, mod.LOADERS, mod.NB, mod.CS) == (64, 3, 6, 68)
