@@ -13,11 +13,12 @@ namespace mi {
 // ---- auto hub threshold of the default (exact-order) mode ------------------------------------------------------
 // Two kernels take rows in stored order: the segment kernel (one lane group per row, 32 gathers in flight: 47 ns per
 // nonzero of ONE row on an idle chip, ~200 ns beside a rows kernel that saturates the fabric; but thousands of rows at
-// once, i.e. full memory throughput) and the hub kernel (6.5 ns per nonzero of one row, about half the segment kernel's
+// once, i.e. full memory throughput) and the hub kernel (4.1 ns per nonzero of one row, about half the segment kernel's
 // throughput).  So: a row becomes a hub when, as a segment on its side stream, it could no longer hide behind the rest of
 // the step -- L x 200 ns > half the step's estimated time (gather-model bytes at 6 TB/s) -- unless the rows above that
 // length hold more than a quarter of all nonzeros: then the hub kernel would carry the step at its lower throughput, and the
-// threshold moves up until they do not (ddi-shaped graphs: every row is long).  Candidates 256 .. 8192, powers of two.
+// threshold moves up until they do not (ddi-shaped graphs: every row is long) -- as long as a segment of that length still fits
+// inside the step (below).  Candidates 256 .. 8192, powers of two.
 // Measured against fixed thresholds on eight graph shapes x three widths: profiles/r03_hub_thresholds.txt.
 // The histogram comes from the same pass over row_ptr that finds the longest row; both plan builders use this function.
 constexpr int kHistN = 6;
@@ -32,7 +33,12 @@ __host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M,
     const double t = 0.5 * (bytes / 6e12) / 200e-9;
     int i = 0;
     while (i + 1 < kHistN && (double)hist_threshold(i + 1) <= t) ++i;
+    const int i_lat = i;
     while (i + 1 < kHistN && (double)nnz_above[i] > 0.25 * (double)nnz) ++i;
+    // ... but not so far up that ONE segment of that length, even on an idle chip (47 ns per nonzero), outlasts the whole step's
+    // estimate: a small matrix of long rows (ddi-shaped, N = 32: 4 267 rows, 44 us of bytes, an 1 772-nonzero row = 83 us as a
+    // segment) is then latency-bound whatever the hub kernel's throughput, and the shorter chain wins (69 -> 42 us)
+    while (i > i_lat && (double)hist_threshold(i) * 47e-9 > bytes / 6e12) --i;
     return hist_threshold(i);
 }
 

@@ -88,7 +88,8 @@ def expected(oracle, ptr, idx, vals, B, split=0, thr=1 << 30, chunk=256):
 def auto_hub_threshold(M, N, ptr):
     """plan.hpp resolve_hub_threshold restated: the auto rule for "long_row_threshold" in the default (exact-order) mode.
     Largest power of two in 256 .. 8192 not above half the step's estimated time (gather-model bytes at 6 TB/s) at 200 ns per
-    nonzero, moved up while the rows above it hold more than a quarter of the nonzeros."""
+    nonzero, moved up while the rows above it hold more than a quarter of the nonzeros (as long as a segment of that
+    length, at 47 ns per nonzero, still fits inside the step's estimate)."""
     if N < 4:
         return (1 << 31) - 1
     deg = np.diff(ptr).astype(np.int64)
@@ -98,6 +99,10 @@ def auto_hub_threshold(M, N, ptr):
     i = 0
     while i + 1 < 6 and cand[i + 1] <= t:
         i += 1
+    i_lat = i
     while i + 1 < 6 and float(deg[deg > cand[i]].sum()) > 0.25 * nnz:
         i += 1
+    step = (nnz * (4.0 * N + 8.0) + 4.0 * M * N) / 6e12
+    while i > i_lat and cand[i] * 47e-9 > step:      # ... but never so far that one idle-chip segment outlasts the step
+        i -= 1
     return cand[i]
