@@ -121,14 +121,14 @@ const char *mi_spmm_strerror(int code);
  *                         64, or 32 when the longest row exceeds 8x the mean degree; get returns the
  *                         resolved value after preprocess).  Scheduling only: results do not depend on it
  *   "long_row_threshold"  rows with more nonzeros are HUBS: they leave the segment kernel for the hub kernel (stored order:
- *                         loader waves + one chain wave per 32-column slice, 6.5 ns per nonzero of a row instead of 47).
+ *                         loader waves + one chain wave per 32-column slice, 4.1 ns per nonzero of a row instead of 47).
  *                         0 = auto: a power of two in 256 .. 8192 from the row-length histogram (hpc_amd/csrc/plan.hpp
  *                         resolve_hub_threshold); get returns the resolved value after preprocess.  Scheduling only in
  *                         the default mode: results do not depend on it
  *   "split_long_rows"     0 (default): hubs keep their stored order.  1: hubs are cut into pieces of "long_row_chunk"
  *                         nonzeros whose partial sums are added left to right (deterministic, not the reference's order;
  *                         auto threshold then clamp(nnz/8192, 256, 2048)).  Faster only when one row holds a few per cent
- *                         of a small matrix (an exact chain cannot run faster than 5.4 cycles per nonzero of that row)
+ *                         of a small matrix (an exact chain cannot run faster than ~5 cycles per nonzero of that row)
  *   "long_row_chunk"      piece length in nonzeros (split mode)
  *   "hub_slice"           columns per hub workgroup: 16, 32, 64; 0 = auto (32; 16 when N <= 16 or when the longest
  *                         row's chain alone is more than half of the step)
