@@ -12,10 +12,10 @@ namespace mi {
 
 // ---- auto hub threshold of the default (exact-order) mode ------------------------------------------------------
 // Two kernels take rows in stored order: the segment kernel (one lane group per row, 32 gathers in flight: 47 ns per
-// nonzero of ONE row on an idle chip, ~200 ns beside a rows kernel that saturates the fabric; but thousands of rows at
+// nonzero of ONE row on an idle chip, 140-430 ns beside a rows kernel that saturates the fabric; but thousands of rows at
 // once, i.e. full memory throughput) and the hub kernel (4.1 ns per nonzero of one row, about half the segment kernel's
 // throughput).  So: a row becomes a hub when, as a segment on its side stream, it could no longer hide behind the rest of
-// the step -- L x 200 ns > half the step's estimated time (gather-model bytes at 6 TB/s) -- unless the rows above that
+// the step -- L x (100 + 1.3 N) ns > half the step's estimated time (gather-model bytes at 6 TB/s) -- unless the rows above that
 // length hold more than a quarter of all nonzeros: then the hub kernel would carry the step at its lower throughput, and the
 // threshold moves up until they do not (ddi-shaped graphs: every row is long) -- as long as a segment of that length still fits
 // inside the step (below).  Candidates 256 .. 8192, powers of two.
@@ -30,7 +30,10 @@ struct LenHist {
 __host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M, int32_t N, const unsigned long long *nnz_above)
 {
     const double bytes = (double)nnz * (4.0 * N + 8.0) + 4.0 * (double)M * N;
-    const double t = 0.5 * (bytes / 6e12) / 200e-9;
+    // a segment's cost per nonzero beside a saturating rows kernel grows with the bytes per gather: ~140 ns at N = 32, ~270 at 128,
+    // ~430 at 256 (am-shaped N = 256: spmm_chunks 0.88 ms for 2 048-nonzero rows, profiles/r03b_am_kernel_stats.csv)
+    const double seg_ns = 100.0 + 1.3 * (double)(N < 256 ? N : 256);
+    const double t = 0.5 * (bytes / 6e12) / (seg_ns * 1e-9);
     int i = 0;
     while (i + 1 < kHistN && (double)hist_threshold(i + 1) <= t) ++i;
     const int i_lat = i;

@@ -87,14 +87,14 @@ def expected(oracle, ptr, idx, vals, B, split=0, thr=1 << 30, chunk=256):
 
 def auto_hub_threshold(M, N, ptr):
     """plan.hpp resolve_hub_threshold restated: the auto rule for "long_row_threshold" in the default (exact-order) mode.
-    Largest power of two in 256 .. 8192 not above half the step's estimated time (gather-model bytes at 6 TB/s) at 200 ns per
+    Largest power of two in 256 .. 8192 not above half the step's estimated time (gather-model bytes at 6 TB/s) at (100 + 1.3 N) ns per
     nonzero, moved up while the rows above it hold more than a quarter of the nonzeros (as long as a segment of that
     length, at 47 ns per nonzero, still fits inside the step's estimate)."""
     if N < 4:
         return (1 << 31) - 1
     deg = np.diff(ptr).astype(np.int64)
     nnz = int(deg.sum())
-    t = 0.5 * ((nnz * (4.0 * N + 8.0) + 4.0 * M * N) / 6e12) / 200e-9
+    t = 0.5 * ((nnz * (4.0 * N + 8.0) + 4.0 * M * N) / 6e12) / ((100.0 + 1.3 * min(N, 256)) * 1e-9)
     cand = [256 << i for i in range(6)]
     i = 0
     while i + 1 < 6 and cand[i + 1] <= t:
