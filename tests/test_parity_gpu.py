@@ -174,6 +174,55 @@ def test_hub_kernel_stage_and_ring_boundaries(device, oracle, N):
         assert np.array_equal(bits(C), bits(exp)), (opts, [lens[i] for i in np.nonzero((bits(C) != bits(exp)).any(axis=1))[0]])
 
 
+def test_hub_rows_of_random_lengths(device, oracle):
+    """Seeded random hub lengths (0 .. 30 000, with the multiples of the 64-nonzero stage and of the six-slot ring over-represented),
+    random widths and slice widths, row-range calls: the chain wave's assembly loop (hub_chain_asm.inc) enters, wraps and leaves its
+    six unrolled copies at every residue -- always the plain oracle's bits."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    n_cases = int(os.environ.get("MI_SPMM_HUB_FUZZ_CASES", "6"))          # soak: MI_SPMM_HUB_FUZZ_CASES=300
+    g = np.random.Generator(np.random.Philox(key=[6464, int(os.environ.get("MI_SPMM_FUZZ_SEED", "1"))]))
+    for case in range(n_cases):
+        K = int(g.integers(2000, 9000))
+        N = int(g.choice([4, 8, 17, 32, 48, 64, 100, 128, 200, 256]))
+        lens = []
+        for _ in range(int(g.integers(4, 14))):
+            kind = int(g.integers(0, 4))
+            if kind == 0:
+                lens.append(int(g.integers(0, 30000)))
+            elif kind == 1:
+                lens.append(64 * int(g.integers(0, 200)) + int(g.choice([0, 0, 1, 63, 31, 32, 33])))
+            elif kind == 2:
+                lens.append(384 * int(g.integers(0, 40)) + int(g.choice([0, 64, 65, 383, 1])))
+            else:
+                lens.append(int(g.integers(0, 80)))
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        idx = g.integers(0, K, size=int(ptr[-1])).astype(np.int32)
+        vals = synth.normal_f32(idx.size, 6500 + case)
+        B = synth.normal_f32(K * N, 6600 + case).reshape(K, N)
+        exp = oracle.spmm_omp(ptr, idx, vals, B)
+        M = len(lens)
+        opts = {"long_row_threshold": int(g.choice([30, 64, 200])), "medium_row_threshold": 8, "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3]}
+        d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+        d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+        for k, v in opts.items():
+            op.set_option(k, v)
+        op.preprocess(d_B, d_C)
+        if case % 2 and M > 2:
+            cut = int(g.integers(1, M))
+            op.run_rows(d_B, N, d_C, N, 0, cut)
+            op.run_rows(d_B, N, d_C, N, cut, M)
+        else:
+            op.run(d_B, d_C)
+        torch.cuda.synchronize()
+        got = d_C.cpu().numpy()
+        assert op.get_option("n_hub_rows") == (sum(1 for x in lens if x > opts["long_row_threshold"]) if N >= 4 else 0)
+        bad = np.nonzero((bits(got) != bits(exp)).any(axis=1))[0]
+        assert bad.size == 0, (case, N, opts, [lens[i] for i in bad])
+
+
 def test_power_law_rows(device, oracle):
     ptr, idx = synth.csr_powerlaw(20000, 32.0, 4096, seed=5)
     vals = synth.normal_f32(idx.size, 6)
