@@ -223,6 +223,31 @@ def test_hub_rows_of_random_lengths(device, oracle):
         assert bad.size == 0, (case, N, opts, [lens[i] for i in bad])
 
 
+def test_hub_segment_and_short_rows_with_special_values(device, oracle):
+    """inf / NaN / -0 / subnormals / near-overflow values in A and B on hub rows (the assembly chain loop), medium rows (segments)
+    and short rows: the same bits as the plain oracle wherever it is a number, NaN wherever it is NaN -- no flush to zero, no
+    reordering that would turn inf - inf into something else."""
+    lens = [5000, 1000, 449, 384, 200, 129, 64, 40, 12, 3, 0, 700, 65]
+    K, g = 3000, np.random.Generator(np.random.Philox(key=[818, 1]))
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = g.integers(0, K, size=int(ptr[-1])).astype(np.int32)
+    special = np.array([np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-40, -3e-42, 1.1754942e-38, 3.4e38, -3.4e38, 1e-30, -1e-30], np.float32)
+    for N in (32, 100, 256):
+        vals = synth.normal_f32(idx.size, 819)
+        B = synth.normal_f32(K * N, 820).reshape(K, N).copy()
+        vals[g.integers(0, vals.size, 300)] = special[g.integers(0, special.size, 300)]
+        B.reshape(-1)[g.integers(0, B.size, 3000)] = special[g.integers(0, special.size, 3000)]
+        ref = oracle.spmm_omp(ptr, idx, vals, B)
+        assert np.isnan(ref).any() and np.isinf(ref).any()
+        for opts in ({"hub_slice": 0}, {"hub_slice": 16}, {"hub_slice": 64}):
+            o = {"long_row_threshold": 128, "medium_row_threshold": 8}
+            o.update(opts)
+            C, op = run_spmm(device, ptr, idx, vals, B, options=o, num_cols=K)
+            assert op.get_option("n_hub_rows") == sum(1 for x in lens if x > 128) and op.get_option("n_medium_rows") > 0
+            same = (bits(C) == bits(ref)) | (np.isnan(C) & np.isnan(ref))
+            assert same.all(), (N, opts, int((~same).sum()))
+
+
 def test_power_law_rows(device, oracle):
     ptr, idx = synth.csr_powerlaw(20000, 32.0, 4096, seed=5)
     vals = synth.normal_f32(idx.size, 6)
