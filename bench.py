@@ -435,10 +435,11 @@ def main():
         if not multi and os.path.exists(tp):
             try:
                 tj = json.load(open(tp)).get(name)          # one entry per configuration (C1, C4, ...)
-                if tj and tj.get("N") == n_total:
+                if tj and tj.get("N") == n_total and M == tj.get("M", 1 << 20):      # the counters of THIS workload, not of a down-sized one
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = {"file": tj.get("source"), "commit": tj.get("commit"), "note": "measured by rocprofv3 --pmc passes of this "
-                                      "command at that commit (scripts/prof.sh), not by this run; FETCH_SIZE x2 + WRITE_SIZE, L2 fabric side"}
+                                      "command at that commit (scripts/prof.sh), not by this run; FETCH_SIZE x2 + WRITE_SIZE, L2 fabric side",
+                                      **traffic_staleness(tj)}
             except Exception:
                 traffic = None
         n_long = op.get_option("n_long_rows")
@@ -514,6 +515,17 @@ def main():
         dist.destroy_process_group()
 
 
+def traffic_staleness(entry):
+    """Is a profiles/traffic_latest.json entry about the kernels this run executes?  The entry carries the sha256 of the
+    kernel sources it was measured on (hpc_amd/_lib.py KERNEL_SOURCES); `traffic_stale` = that hash is absent or differs
+    from the tree bench.py runs from -- the counters then describe an earlier kernel and say so in the line."""
+    from hpc_amd._lib import kernel_sources_sha256
+
+    here, there = kernel_sources_sha256(), entry.get("kernel_sources_sha256")
+    return {"traffic_stale": bool(here is None or there is None or here != there),
+            "kernel_sources_sha256": {"measured": there, "this_run": here}}
+
+
 def also_configs(args, dev, c1_tensors, M):
     """C2, C4 and C1-at-N=1024 on this GPU, one after the other, each: preprocess (untimed), 3 warm-up runs, args.steps
     timed runs back to back between one HIP event pair on the launch stream (the headline's protocol).  Values and B are N(0, 0.1) filled on the device
@@ -561,8 +573,8 @@ def also_configs(args, dev, c1_tensors, M):
         flops = 2.0 * nnz * n
         tj = traffic_file.get(tag)
         traffic = tj.get("hbm_bytes_per_launch") if tj and tj.get("N") == n and M == (1 << 20) else None
-        src = ({"file": tj.get("source"), "commit": tj.get("commit"), "note": "rocprofv3 --pmc passes at that commit, not this run"}
-               if traffic is not None else None)
+        src = ({"file": tj.get("source"), "commit": tj.get("commit"), "note": "rocprofv3 --pmc passes at that commit, not this run",
+                **traffic_staleness(tj)} if traffic is not None else None)
         n_blk = op.get_option("n_block_groups")
         if n_blk * 16 * 2 > M:
             tf = flops / (ms * 1e-3) / 1e12

@@ -39,6 +39,25 @@ SIGNATURES = {
 
 _lib = None
 
+# The kernel sources a measured profile describes: profiles/traffic_latest.json stores this hash beside the counters
+# (scripts/summarize_prof.py) and bench.py compares it with the tree it runs from ("traffic_stale").
+KERNEL_SOURCES = ("spmm_kernels.hpp", "mi_spmm.hip", "hub_chain_asm.inc")
+
+
+def kernel_sources_sha256():
+    """sha256 over the kernel sources (names and contents, in KERNEL_SOURCES order); None when the tree has no sources."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        path = os.path.join(_HERE, "csrc", name)
+        if not os.path.exists(path):
+            return None
+        h.update(name.encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
 
 class MiSpmmLibraryMissing(RuntimeError):
     pass

@@ -990,7 +990,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     // The hub kernel goes first (its longest row is the step's longest dependent chain) and, like the block kernel,
     // addresses the full width: it is launched with the first column part only.
     if (h->n_long > 0 && !h->split_long && launch_blocks_here) {
-        HubArgs ha;
+        HubArgs ha{};
         ha.rows = h->d_long;
         ha.row_ptr = h->d_ptr;
         ha.col_idx = h->d_idx;
@@ -1029,7 +1029,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ++launches;
     }
     if (h->n_chunks > 0) {
-        ChunkArgs ca;
+        ChunkArgs ca{};
         ca.chunks = h->d_chunks;
         ca.col_idx = h->d_idx;
         ca.vals = h->d_val;
@@ -1066,7 +1066,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     const bool wide_full = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
                              ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
     if (blocks_on && launch_blocks_here) {
-        BlockArgs ba;
+        BlockArgs ba{};
         ba.col_idx = h->d_idx;
         ba.vals = h->d_val;
         ba.B = full.B;
@@ -1097,7 +1097,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         }
     }
 
-    RowsArgs a;
+    RowsArgs a{};
     a.blk_flag = h->n_blk_groups > 0 ? h->d_blk_flag : nullptr;
     a.row_ptr = h->d_ptr;
     a.col_idx = h->d_idx;
@@ -1126,7 +1126,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     if (rows_needed) ++launches;
 
     if (h->n_long > 0 && h->split_long) {
-        ReduceArgs ra;
+        ReduceArgs ra{};
         ra.rows = h->d_long;
         ra.partials = h->d_partials + col0;
         ra.C = d_vout;

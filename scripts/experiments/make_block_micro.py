@@ -74,7 +74,7 @@ int main()
         for (int pass = 0; pass < h->n_blk_passes; ++pass) {
             const int n = h->blk_launch[pass][2].n, off = h->blk_launch[pass][2].off;
             if (n == 0) continue;
-            BlockArgs ba; ba.items = h->d_blk_items + off; ba.col_idx = d_idx; ba.vals = d_val; ba.B = d_B; ba.C = d_C; ba.ldb = N; ba.ldc = N; ba.n_items = n; ba.N = N;
+            BlockArgs ba{}; ba.items = h->d_blk_items + off; ba.col_idx = d_idx; ba.vals = d_val; ba.B = d_B; ba.C = d_C; ba.ldb = N; ba.ldc = N; ba.n_items = n; ba.N = N;
             ba.remap = 1; ba.row_lo = 0; ba.row_hi = M; std::memset(&ba.po, 0, sizeof(ba.po));
             hipLaunchKernelGGL((spmm_block_items_stamped<4, 4, 2, false, true>), dim3((n + wpw - 1) / wpw), dim3(64 * wpw), 0, 0, ba, d_dbg + (size_t)off * 8);
         }

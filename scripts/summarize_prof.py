@@ -78,6 +78,9 @@ def main():
         ent = {"source": f"profiles/{tag}_profile.json",
                "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown",
                "hbm_bytes_per_launch": step["traffic_bytes"], "fetch_bytes_x2": step["fetch_bytes_x2"], "write_bytes": step["write_bytes"]}
+        sys.path.insert(0, ROOT)
+        from hpc_amd._lib import kernel_sources_sha256
+        ent["kernel_sources_sha256"] = kernel_sources_sha256()      # bench.py: "traffic_stale" when the tree's differs
         if "--feat" in sys.argv:
             ent["N"] = int(sys.argv[sys.argv.index("--feat") + 1])
         for k in ("l2_hit_rate", "mfma_busy_frac"):

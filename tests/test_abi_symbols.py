@@ -176,3 +176,55 @@ def test_generated_hub_chain_assembly_is_in_sync_with_its_generator():
     for decl in ("static constexpr int ST = 64;", "static constexpr int L = 3;", "static constexpr int CS = ST + 4;", "static constexpr int NB = 2 * L;"):
         assert decl in src, decl
     assert (mod.ST, mod.LOADERS, mod.NB, mod.CS) == (64, 3, 6, 68)
+
+
+def test_kernel_argument_structs_are_value_initialised():
+    """Every kernel-argument struct (`*Args`) handed to a launch is declared `T x{};`.  Round 3's hub_micro experiment
+    declared `HubArgs a;`, set every field but `a.po` (added to the struct later) and the kernel's epilogue stored through
+    the stack garbage in it: a GPU memory fault under the profiler's preload.  A field added to a struct tomorrow must
+    start as zero everywhere the struct is built -- product, experiments and native tests alike."""
+    import glob
+
+    pats = [os.path.join(ROOT, "hpc_amd", "csrc", "*.hip"), os.path.join(ROOT, "hpc_amd", "csrc", "*.cpp"),
+            os.path.join(ROOT, "scripts", "experiments", "make_*.py"), os.path.join(ROOT, "scripts", "experiments", "*.hip"),
+            os.path.join(ROOT, "tests", "native", "*.cpp"), os.path.join(ROOT, "oracle", "*.hip")]
+    bare = re.compile(r"\b(\w*Args)\s+(\w+)\s*;")        # `HubArgs a;` -- a declaration with no initialiser
+    seen = 0
+    for pat in pats:
+        for path in glob.glob(pat):
+            for no, line in enumerate(open(path), 1):
+                if line.lstrip().startswith(("//", "#", "*")):
+                    continue
+                m = bare.search(line)
+                assert not m, f"{path}:{no}: `{m.group(0)}` leaves fields uninitialised: write `{m.group(1)} {m.group(2)}{{}};`"
+                seen += len(re.findall(r"\b\w*Args\s+\w+\{\};", line))
+    assert seen >= 7, "expected the product's five launch sites and the two experiment drivers"
+    # the generated experiment sources are the generators' output as committed
+    for gen, out in (("make_hub_micro.py", "hub_micro.hip"), ("make_block_micro.py", "block_micro.hip")):
+        src = open(os.path.join(ROOT, "scripts", "experiments", out)).read()
+        assert re.search(r"\b\w*Args \w+\{\};", src), f"{out}: regenerate it with scripts/experiments/{gen}"
+
+
+def test_traffic_entries_carry_a_kernel_source_hash_and_bench_flags_stale_ones():
+    """bench.py quotes PMC traffic measured by an earlier profile run (profiles/traffic_latest.json).  Round 3's C4 entry
+    described a kernel that had been replaced afterwards and nothing in the line said so: every entry now carries the sha256
+    of the kernel sources it was measured on, and the line says `traffic_stale` when the tree's differ."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from hpc_amd._lib import KERNEL_SOURCES, kernel_sources_sha256
+
+    here = kernel_sources_sha256()
+    assert here and len(here) == 64 and set(KERNEL_SOURCES) == {"spmm_kernels.hpp", "mi_spmm.hip", "hub_chain_asm.inc"}
+    assert bench.traffic_staleness({"kernel_sources_sha256": here})["traffic_stale"] is False
+    assert bench.traffic_staleness({"kernel_sources_sha256": "0" * 64})["traffic_stale"] is True
+    assert bench.traffic_staleness({})["traffic_stale"] is True                       # entries from before round 4
+    st = bench.traffic_staleness({"kernel_sources_sha256": "0" * 64})
+    assert st["kernel_sources_sha256"] == {"measured": "0" * 64, "this_run": here}
+    tl = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    for key, ent in tl.items():
+        for k in ("source", "commit", "hbm_bytes_per_launch", "N"):
+            assert k in ent, (key, k)
+        assert os.path.exists(os.path.join(ROOT, ent["source"])), ent["source"]

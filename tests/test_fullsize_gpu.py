@@ -168,8 +168,11 @@ def test_c2_power_law_full_size(device, oracle):
     rel = np.abs(got[split_sel].astype(np.float64) - plain[split_sel]) / np.maximum(np.abs(plain[split_sel].astype(np.float64)), 1e-300)
     print(f"C2 split mode, {int(split_sel.sum())} split rows: plain relative error max {rel.max():.3e}, p99.9 {np.quantile(rel, 0.999):.3e}, "
           f"share > 1e-5: {(rel > 1e-5).mean():.5f}")
-    ndiff_split, _ = count_bitdiff(d_S, d_R)                   # only elements of split rows may differ
-    assert ndiff_split <= hubs.size * N
+    ndiff_split, _ = count_bitdiff(d_S, d_R)                   # only elements of split rows may differ -- and some of them must:
+    assert 0 < ndiff_split <= hubs.size * N                    # a counter stuck at 0 would pass every `== 0` above
+    # the device counter against numpy on the split rows themselves (every other row is bit-identical, asserted by the bound above)
+    ref_rows = d_R[hubs.tolist()].cpu().numpy()
+    assert ndiff_split == int((bits(d_S[hubs.tolist()].cpu().numpy()) != bits(ref_rows)).sum())
 
 
 # name: (rows, nonzeros, longest row) -- shapes of the reference's datasets (scripts/report_table.py), N
@@ -278,3 +281,51 @@ def test_c3_one_gpu_leg_n1024_at_the_narrow_address_boundary(device, oracle):
     torch.cuda.synchronize()
     ndiff, maxabs = count_bitdiff(d_C, d_R)
     assert ndiff == 0 and maxabs == 0.0
+
+
+def test_count_bitdiff_sees_planted_differences(device):
+    """Every whole-C equality claim of this file rests on `count_bitdiff` (mi_spmm_count_bitdiff -> compare_kernel mode 2, the
+    exact counterpart of the reference's validate_int, W/src/valid.cu:13-20).  Here the judge is judged: two 2^26-element
+    buffers that differ in k planted places -- first and last element, a +0 / -0 pair (equal as floats, different bits), a
+    pair of NaNs with different payloads, a denormal against zero, neighbours in one wave, places 2^24 apart (beyond one
+    grid stride) -- must give exactly k, and the largest |a - b| numpy finds."""
+    import torch
+    from hpc_amd.spmm import count_bitdiff, valid
+
+    n = 1 << 26
+    g = np.random.Generator(np.random.Philox(key=[404, 1]))
+    a = torch.empty(n, dtype=torch.float32, device=device).normal_(0.0, 0.1)
+    b = a.clone()
+    assert count_bitdiff(a, b) == (0, 0.0)
+    places = np.unique(np.concatenate([[0, 1, 63, 64, 65, 255, 256, n - 1, n - 2, 1 << 24, (1 << 24) + 1, (1 << 25) + 7],
+                                       g.integers(0, n, 1000)])).astype(np.int64)
+    k = int(places.size)
+    hb = b[places.tolist()].cpu().numpy().copy()
+    ha = a[places.tolist()].cpu().numpy().copy()
+    hb = hb + np.float32(0.25) * (1 + (np.arange(k) % 7)).astype(np.float32)     # finite, exactly representable offsets: every place differs
+    # +0 against -0 at place index 3: a bit difference with |a - b| == 0
+    ha[3], hb[3] = np.float32(0.0), np.float32(-0.0)
+    # a denormal against zero at place index 5
+    ha[5], hb[5] = np.float32(0.0), np.frombuffer(np.uint32(1).tobytes(), np.float32)[0]
+    a[places.tolist()] = torch.from_numpy(ha).to(device)
+    b[places.tolist()] = torch.from_numpy(hb).to(device)
+    assert (bits(ha) != bits(hb)).all()
+    ndiff, maxabs = count_bitdiff(a, b)
+    assert ndiff == k, (ndiff, k)
+    assert maxabs == float(np.abs(ha - hb).max()) > 0.25       # fp32 subtraction on both sides
+    assert count_bitdiff(b, a) == (ndiff, maxabs)
+    # the reference's float rule on the same buffers (valid.cu:6: |(ref - ans) / ref| > 1e-2) against numpy
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.abs((ha - hb) / ha)
+    assert valid(a, b, n) == int((q.astype(np.float64) > 1e-2).sum())
+    # a NaN pair with different payloads: counted, and the maximum is reported as inf (a NaN took part)
+    nan_a = np.frombuffer(np.uint32(0x7FC00001).tobytes(), np.float32)[0]
+    nan_b = np.frombuffer(np.uint32(0x7FC00002).tobytes(), np.float32)[0]
+    a2, b2 = a.clone(), a.clone()
+    a2[n - 1], b2[n - 1] = float("nan"), float("nan")
+    a2.view(torch.int32)[n - 1], b2.view(torch.int32)[n - 1] = 0x7FC00001, 0x7FC00002
+    assert np.isnan(nan_a) and np.isnan(nan_b)
+    nd, mx = count_bitdiff(a2, b2)
+    assert nd == 1 and mx == float("inf")
+    a2.view(torch.int32)[n - 1] = 0x7FC00002            # same NaN bits on both sides: no difference
+    assert count_bitdiff(a2, b2) == (0, 0.0)
