@@ -91,6 +91,26 @@ def csr_powerlaw(M, mean_deg=32.0, max_deg=4096, alpha=1.5, K=None, seed=SEED_ST
     return _finish_rows(M, K, deg, g)
 
 
+# The reference's 13 course graphs (W/script/run_all.sh:3) are not in its repository; their longest rows are (W/phase_2.log).
+# name: (rows, nonzeros, longest row).  Rows / nonzeros are the public OGB / DGL / CogDL statistics of the datasets of those
+# names (approximate; stated here, not taken from the reference).
+DATASET_SHAPES = {
+    "arxiv": (169_343, 1_166_243, 13_155), "collab": (235_868, 2_358_104, 671), "citation": (2_927_963, 30_387_995, 1_738),
+    "ddi": (4_267, 2_135_822, 2_234), "protein": (132_534, 79_122_504, 7_750), "ppa": (576_289, 42_463_862, 3_241),
+    "reddit.dgl": (232_965, 114_615_892, 21_657), "products": (2_449_029, 123_718_280, 17_481),
+    "youtube": (1_138_499, 5_980_886, 28_754), "amazon_cogdl": (1_569_960, 264_339_468, 75_134),
+    "yelp": (716_847, 13_954_819, 4_886), "wikikg2": (2_500_604, 16_109_182, 911), "am": (881_680, 5_668_682, 154_828),
+}
+
+
+def csr_dataset_shaped(name):
+    """A stand-in with the SHAPE of one of the reference's datasets: that many rows and nonzeros, a power-law degree profile
+    whose longest row is the logged one, uniformly random columns (no community structure: harsher on caches than the real
+    graph).  scripts/report_table.py, scripts/hub_bench.py, `bench.py --config am` and the full-size tests use this one."""
+    M, nnz_target, max_deg = DATASET_SHAPES[name]
+    return csr_powerlaw(M, nnz_target / M, min(max_deg, M), seed=sum(map(ord, name)) % 1000 + 1, force_max=True)
+
+
 def csr_block_dense(M, rows_per_block=16, run_lo=64, run_hi=128, max_runs=2, K=None, seed=SEED_STRUCT):
     """C4: rows in blocks of `rows_per_block` share 1..max_runs aligned contiguous column runs
     of 64..128 columns (run start and length multiples of 64/..: aligned to 64); every row of a

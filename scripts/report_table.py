@@ -24,22 +24,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# name: (rows, nonzeros, max row length from W/phase_2.log)
-DATASETS = [
-    ("arxiv", 169_343, 1_166_243, 13_155),
-    ("collab", 235_868, 2_358_104, 671),
-    ("citation", 2_927_963, 30_387_995, 1_738),
-    ("ddi", 4_267, 2_135_822, 2_234),
-    ("protein", 132_534, 79_122_504, 7_750),
-    ("ppa", 576_289, 42_463_862, 3_241),
-    ("reddit.dgl", 232_965, 114_615_892, 21_657),
-    ("products", 2_449_029, 123_718_280, 17_481),
-    ("youtube", 1_138_499, 5_980_886, 28_754),
-    ("amazon_cogdl", 1_569_960, 264_339_468, 75_134),
-    ("yelp", 716_847, 13_954_819, 4_886),
-    ("wikikg2", 2_500_604, 16_109_182, 911),
-    ("am", 881_680, 5_668_682, 154_828),
-]
+from hpc_amd.synth import DATASET_SHAPES, csr_dataset_shaped   # name: (rows, nonzeros, max row length from W/phase_2.log)
+
+DATASETS = [(n, *v) for n, v in DATASET_SHAPES.items()]
 
 
 def timed(f, warm, reps):
@@ -74,7 +61,7 @@ def main():
         if args.only and args.only not in name:
             continue
         t = time.time()
-        ptr, idx = synth.csr_powerlaw(M, nnz_target / M, min(max_deg, M), seed=sum(map(ord, name)) % 1000 + 1, force_max=True)
+        ptr, idx = csr_dataset_shaped(name)
         nnz = int(idx.size)
         deg = np.diff(ptr)
         vals = synth.make_values(nnz)

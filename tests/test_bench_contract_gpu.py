@@ -64,8 +64,59 @@ def test_multi_gpu_path_rehearsal(exchange):
     assert "error" not in b and b["compute_only_ms"] > 0 and b["exchange_only_ms"] > 0 and b["exchange"] == exchange
     assert (b["staging_bytes"] > 0) == (exchange not in ("peer2d", "peer_store")) and "strong_reference_ms" in d and d["strong_reference_ms"] > 0
     assert d["cpu_baseline"] is None
+    assert d["exchange"] == exchange and d["exchange_selection"]["rule"] == f"fixed by --exchange {exchange}"
+    assert abs(d["speedup_vs_one_gpu"] - d["strong_reference_ms"] / d["ms_per_step"]) < 2e-3
     r = d["roofline"]        # N>1: the same per-GPU kernel, timed on the compute-only leg
     assert r["bound"] == "hbm" and r["traffic"] is None and abs(r["kernel_ms"] - b["compute_only_ms"]) < 1e-3
+
+
+def test_multi_gpu_default_is_safe_first_auto():
+    """`bench.py --gpus N` with default flags (what the driver runs): the contract line is first measured on the RCCL all-gather
+    (the safe schedule) and kept in hand, then direct / peer2d / peer_store are tried under the watchdog; the line says which
+    schedule it was finally measured on and carries the all-gather's figures beside it."""
+    d = _run("--rehearse-multi", "--no-cpu-baseline", "--check", "--panels", "3")
+    assert d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
+    sel = d["exchange_selection"]
+    assert sel["safe_schedule"] == "allgather" and sel["safe_schedule_ms_per_step"] > 0 and "safe-first" in sel["rule"]
+    tuning = sel["exchange_tuning_ms_per_step"]
+    assert {"allgather", "direct", "peer2d", "peer_store"} <= set(tuning) and all(tuning[k] > 0 for k in ("allgather", "direct", "peer2d", "peer_store"))
+    assert d["exchange"] in ("allgather", "direct", "peer2d", "peer_store") and d["multi_gpu_breakdown"]["exchange"] == d["exchange"]
+    if d["exchange"] != "allgather":                 # re-measured with the contract protocol, and faster than the safe schedule
+        assert d["ms_per_step"] < sel["safe_schedule_ms_per_step"] and (d["exchange"] + " (contract protocol)") in tuning
+    else:
+        assert abs(d["ms_per_step"] - sel["safe_schedule_ms_per_step"]) < 1e-3
+    assert d["strong_reference_ms"] > 0 and abs(d["speedup_vs_one_gpu"] - d["strong_reference_ms"] / d["ms_per_step"]) < 2e-3
+    assert "exchange_watchdog" not in d
+
+
+def test_multi_gpu_candidate_that_throws_is_dropped():
+    d = _run("--rehearse-multi", "--no-cpu-baseline", "--panels", "3", MI_SPMM_FORCE_FAIL_EXCHANGE="direct")
+    tuning = d["exchange_selection"]["exchange_tuning_ms_per_step"]
+    assert tuning["direct"] is None and tuning["allgather"] > 0 and d["exchange"] != "direct" and "exchange_watchdog" not in d
+
+
+def test_multi_gpu_candidate_that_hangs_still_yields_the_line_in_hand():
+    """A schedule that neither finishes nor throws (forced: MI_SPMM_FORCE_HANG_EXCHANGE) must not cost the measurement: the
+    per-rank watchdog prints the all-gather line it has in hand, says what hung, and the process leaves (exit code 0: the
+    line is a complete measurement)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", MI_SPMM_FORCE_HANG_EXCHANGE="peer2d", MI_SPMM_WATCHDOG_S="45")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--M", "65536", "--steps", "3", "--warmup", "1", "--rehearse-multi",
+                        "--no-cpu-baseline", "--panels", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout + r.stderr
+    d = json.loads(lines[0])
+    assert r.returncode == 0, r.stderr
+    assert d["exchange"] == "allgather" and "peer2d" in d["exchange_watchdog"]["fired_in"]
+    tuning = d["exchange_selection"]["exchange_tuning_ms_per_step"]
+    assert tuning["allgather"] > 0 and tuning["direct"] > 0 and "peer2d" not in tuning      # direct was tried before the hang
+    assert d["ms_per_step"] > 0 and d["n_gpus"] == 1 and d["steps"] == 3
+    assert "watchdog" in r.stderr and "hanging on purpose" in r.stderr
+    # with MI_SPMM_WATCHDOG_EXIT the same stop can be made to read as a failure
+    env["MI_SPMM_WATCHDOG_EXIT"] = "4"
+    env["MI_SPMM_FORCE_HANG_EXCHANGE"] = "direct"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--M", "65536", "--steps", "2", "--warmup", "1", "--rehearse-multi",
+                        "--no-cpu-baseline", "--panels", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 4 and len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
 
 
 def test_multi_gpu_fallback_to_the_python_schedule():
@@ -91,6 +142,25 @@ def test_driver_launch_line_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["N"] == 256 and d["config"]["cols_per_gpu"] == 128
     assert "rehearsal" in d and d["check"]["bitwise_equal_rows"] == d["check"]["rows"]
-    assert "error" not in d["multi_gpu_breakdown"] and d["multi_gpu_breakdown"]["exchange"] == "peer2d"
-    assert d["strong_reference_ms"] > 0
+    # ranks sharing a GPU cannot use RCCL: the safe schedule is peer2d (IPC copies + host barriers), the candidate peer_store
+    sel = d["exchange_selection"]
+    assert sel["safe_schedule"] == "peer2d" and set(sel["exchange_tuning_ms_per_step"]) >= {"peer2d", "peer_store"}
+    assert "error" not in d["multi_gpu_breakdown"] and d["multi_gpu_breakdown"]["exchange"] == d["exchange"] and d["exchange"] in ("peer2d", "peer_store")
+    assert d["strong_reference_ms"] > 0 and d["speedup_vs_one_gpu"] > 0
     assert abs(d["value"] - 2.0 * d["config"]["nnz"] * 256 / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+
+
+def test_driver_launch_line_two_ranks_with_a_candidate_that_hangs():
+    """The same two-rank launch with the candidate schedule hanging on BOTH ranks: each rank's watchdog fires, rank 0 prints
+    the peer2d line it has in hand, torch.distributed.run sees two clean exits."""
+    env = dict(os.environ, MI_SPMM_SHARE_GPU="1", MI_SPMM_FORCE_HANG_EXCHANGE="peer_store", MI_SPMM_WATCHDOG_S="45")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--M", "65536"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout + r.stderr
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["exchange"] == "peer2d" and "peer_store" in d["exchange_watchdog"]["fired_in"]
+    assert d["ms_per_step"] > 0 and d["config"]["N"] == 256
