@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
     typedef HubCfg<SW> K;
     constexpr int L = K::L, U = K::U, LPS = K::LPS, NG = K::NG, NBK = K::NBK, CS = K::CS, NB = K::NB;
     __shared__ __attribute__((aligned(16))) float ring[K::LDS_BYTES / 4];
-    __shared__ int flags[16];                                   // [w] (w < L): stages loader w has published, in its own order; [L]: stages consumed
+    __shared__ int flags[16];                                   // [0] pub: stages 0 .. pub-1 are in the ring (INT_MAX once the row's last one is); [L] done: stages consumed
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;
@@ -509,29 +509,32 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
         const int cj = lane % SW;
         const int n_full = len / K::ST;          // whole stages; a last partial one is walked element by element
         float acc = 0.f;
-        auto spin_ready = [&](int w2, int need) {            // stage t is loader t % L's stage number t / L
-            while (hub_flag_load(&flags[w2]) < need) __builtin_amdgcn_s_sleep(1);
+        auto spin_ready = [&](int need) {                    // stages 0 .. need-1 are published (the loaders publish in order)
+            while (hub_flag_load(&flags[0]) < need) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         };
         if (n_full > 0) {
-            // The whole stages, in assembly (gen_hub_chain.py -> hub_chain_asm.inc, where the why is written down).  Per stage
-            // of 64 nonzeros and two half-stage register sets: [the 16 reads of the next half stage, back to back]
-            // [32 v_fmac_f32, k ascending] [s_waitcnt lgkmcnt(0): the reads are 32 links old] -- twice; the next stage's
-            // published count rides in front of the first group as a 17th read and is looked at a trip later, the `done`
-            // word is written right behind the reads of the stage's second half.  Unrolled over the ring's six slots: every
-            // address is a base register plus an immediate.
-            spin_ready(0, 1);
-            const uint32_t bb = (uint32_t)(size_t)&ring[cj * CS], rba = (uint32_t)(size_t)&ring[SW * CS];
+            // The whole stages, in assembly (gen_hub_chain.py -> hub_chain_asm.inc, where the why is written down).  Per PAIR of
+            // stages: [pub poll + the 8 B reads of a half stage, back to back] [32 v_fmac_f32_dpp, k ascending] [s_waitcnt
+            // lgkmcnt(0): the reads are 32 links old] -- four times, with ONE read per stage for its 64 a values (lane i of a
+            // 16-lane row holds a[4 i .. 4 i + 3]; link 4 i + r takes its factor from register r of row lane i through DPP), the
+            // poll looked at 32 links after it was fetched and the `done` word written once, behind the reads of the pair's last
+            // half stage.  Unrolled over the ring's six slots: every address is a base register plus an immediate.
+            spin_ready(1);
+            const uint32_t bb = (uint32_t)(size_t)&ring[cj * CS];
+            const uint32_t ra = (uint32_t)(size_t)&ring[SW * CS] + 16u * (uint32_t)(lane & (MI_HUB_CHAIN_A_LANES - 1));
             const uint32_t fl = (uint32_t)(size_t)&flags[0];
             static_assert(L == 3 && NB == 6 && K::ST == 64 && CS == 68, "hub_chain_asm.inc is generated for this ring: re-run gen_hub_chain.py");
-#define MI_HUB_CHAIN(TEXT) asm volatile(TEXT : [acc] "+v"(acc) : [bb] "v"(bb), [rba] "s"(rba), [fl] "s"(fl), [nf] "s"(n_full) : MI_HUB_CHAIN_CLOBBERS)
+            static_assert((SW == 16 ? MI_HUB_CHAIN_SLOT_BYTES_16 : SW == 32 ? MI_HUB_CHAIN_SLOT_BYTES_32 : MI_HUB_CHAIN_SLOT_BYTES_64) == K::SLOT_FLOATS * 4,
+                          "the assembly's slot size is not HubCfg's: re-run gen_hub_chain.py");
+#define MI_HUB_CHAIN(TEXT) asm volatile(TEXT : [acc] "+v"(acc) : [bb] "v"(bb), [ra] "v"(ra), [fl] "s"(fl), [nf] "s"(n_full) : MI_HUB_CHAIN_CLOBBERS)
             if constexpr (SW == 16) MI_HUB_CHAIN(MI_HUB_CHAIN_ASM_16);
             else if constexpr (SW == 32) MI_HUB_CHAIN(MI_HUB_CHAIN_ASM_32);
             else MI_HUB_CHAIN(MI_HUB_CHAIN_ASM_64);
 #undef MI_HUB_CHAIN
         }
         if (n_full < n_st) {                      // the partial last stage
-            spin_ready(n_full % L, n_full / L + 1);
+            spin_ready(n_full + 1);
             const float *bs = &ring[(n_full % NB) * K::SLOT_FLOATS + cj * CS];
             const float *vs = &ring[(n_full % NB) * K::SLOT_FLOATS + SW * CS];
             for (int i = 0; i < len - K::ST * n_full; ++i) acc = __builtin_fmaf(bs[i], vs[i], acc);
@@ -546,14 +549,16 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
     // ---- loaders: wave w takes stages w, w + L, w + 2L, ...
     const int w = wave - 1;
     // Lane -> (16-byte part of the row slice, nonzero group).  In publish() a lane's write for (e, h) starts at 16-byte
-    // granule (4 part + e) (CS / 4) + g + NG h = 4 part + g + const (mod 16: CS / 4 = 17), and the LDS serves a 16-byte
-    // write 16 lanes at a time: the 16 lanes of a quarter wave must differ in 4 part + g (mod 16).  So a quarter wave is
-    // four parts x four groups (part = lane & 3, g = (lane >> 2) & 3) and the lane's upper bits select further parts
-    // first, then further groups.  (part = lane % LPS, g = lane / LPS: conflict-free at SW = 16 only, 2-way at 32,
-    // 4-way at 64 -- and every conflicting write delays the chain wave's reads.)  Four consecutive lanes still fetch 64
-    // contiguous bytes of one B row.
-    constexpr int PH = LPS / 4;                                  // parts beyond the first four, in lane bits 4..
-    const int part = (lane & 3) + 4 * ((lane >> 4) % PH), g = ((lane >> 2) & 3) + 4 * ((lane >> 4) / PH);
+    // granule (4 part + e) (CS / 4) + g + NG h = 4 part + g + const (mod 8: CS / 4 = 17), and the LDS serves a
+    // ds_write_b128 EIGHT contiguous lanes at a time over 32 banks = 8 granules (MI355X_MICROARCH.md, LDS): the 8 lanes
+    // of such a group must differ in 4 part + g (mod 8).  So a group is two parts x four nonzero groups (part = lane & 1,
+    // g = (lane >> 1) & 3) and the lane's upper bits select further parts first, then further groups.  Round 3 reasoned
+    // with 16 lanes over 64 banks (four parts x four groups per quarter wave): SQ_LDS_BANK_CONFLICT counted exactly 4
+    // cycles per write for it, 0 for this one (profiles/r04_hub_lds_counters.txt; part = lane % LPS, g = lane / LPS is
+    // 4-way at SW = 32).  Every conflicting write delays the chain wave's reads.  Two consecutive lanes fetch 32
+    // contiguous bytes of one B row, the lane 8 further on the next 32.
+    constexpr int PH = LPS / 2;                                  // parts beyond the first two, in lane bits 3..
+    const int part = (lane & 1) + 2 * ((lane >> 3) % PH), g = ((lane >> 1) & 3) + 4 * ((lane >> 3) / PH);
     // A slice that sticks out past N (or a width that is no multiple of 4) shifts its last parts back to column N - 4: they
     // re-fetch and recompute columns of their neighbours with identical bits (as in the rows kernel).
     const int colf = min(slice * SW + 4 * part, a.N - 4);
@@ -591,7 +596,11 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
             }
         base[SW * CS + lane] = R.v;
         asm volatile("" ::: "memory");
-        hub_flag_store(&flags[w], s / L + 1);     // behind the data in this wave's LDS queue
+        // Publish IN ORDER: stage s goes out once every earlier stage has (one word tells the chain wave how far it may read:
+        // one poll per pair of stages).  The data above precedes the flag in this wave's LDS queue; the row's last stage writes INT_MAX.
+        while (hub_flag_load(&flags[0]) < s) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        hub_flag_store(&flags[0], s == n_st - 1 ? 0x7fffffff : s + 1);
     };
 
     if (w >= n_st) return;

@@ -135,6 +135,13 @@ const char *mi_spmm_strerror(int code);
  *   "hub_overlap"         1 (default): the hub and segment kernels run on handle-owned side streams forked from and joined
  *                         into the caller's stream inside every run call, when the step is long enough to hide their
  *                         longest rows behind the rows kernel (the fork costs ~20 us); 0: never; 2: always
+ *   "use_graph"           0 (default) / 1: the step's launch set (2-4 kernels plus the side streams' fork and join) is captured once
+ *                         into a HIP graph on a handle-owned stream and run() replays it with ONE hipGraphLaunch on the caller's
+ *                         stream -- for steps of tens of microseconds (small graphs) the launches are the step.  preprocess captures
+ *                         for the vin / vout it is given (the reference hands run() the same buffers, test_spmm.cu:35-40), so run() on
+ *                         them still allocates nothing; a run call with other buffers, pitches, row range or extra destinations
+ *                         re-captures once (that call allocates).  A caller that is itself capturing gets the plain launches.
+ *                         Same kernels, same arguments: same bits.  Read-only: "graph_ready", "graph_captures", "graph_replays"
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
  *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel (8, 16, 32; default 32)

@@ -917,6 +917,85 @@ def test_run_is_graph_capturable_and_stream_ordered(device, oracle, split, overl
     assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
 
 
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_use_graph_replays_the_captured_launch_set(device, oracle, overlap):
+    """ "use_graph" = 1: preprocess captures the step's launch set (hub + segments + rows, side-stream fork / join included)
+    into a HIP graph on a handle-owned stream, for the buffers it is handed -- the reference hands run() the same ones
+    (test_spmm.cu:35-40) -- and run() replays it with one hipGraphLaunch on the caller's stream: same bits, overwrite and
+    idempotent as before, stream-ordered, no allocation in run() for those buffers.  Other buffers, pitches or row ranges
+    re-capture once; a caller that is itself capturing gets the plain (capturable) launches."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx = synth.csr_powerlaw(6000, 24.0, 2000, seed=3)
+    vals = synth.normal_f32(idx.size, 4)
+    B = synth.normal_f32(6000 * 64, 5).reshape(6000, 64)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((6000, 64), float("nan"), device=device)
+    op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
+    op.set_option("long_row_threshold", 512)
+    op.set_option("hub_overlap", overlap)
+    op.set_option("use_graph", 1)
+    assert op.get_option("use_graph") == 1 and op.get_option("graph_ready") == 0
+    op.preprocess(d_B, d_C)
+    assert op.get_option("graph_ready") == 1 and op.get_option("graph_captures") == 1 and op.get_option("graph_replays") == 0
+    exp = expected(oracle, ptr, idx, vals, B)
+    for rep in range(3):                                        # null stream, as the reference runs it
+        d_C.fill_(float("nan"))
+        op.run(d_B, d_C)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    assert op.get_option("graph_replays") == 3 and op.get_option("graph_captures") == 1 and op.get_option("n_launches") == 3
+    # stream order on a caller's stream: fill -> run -> scale must happen in that order, all on `side`
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        d_C.fill_(float("nan"))
+        op.run(d_B, d_C)
+        d_C.mul_(2.0)
+    side.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
+    assert op.get_option("graph_replays") == 4 and op.get_option("graph_captures") == 1
+    # new B CONTENTS, same buffers: the graph holds pointers, not values
+    d_B.mul_(2.0)
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
+    d_B.mul_(0.5)
+    # another output buffer: one re-capture, then replays
+    d_C2 = torch.full((6000, 64), float("nan"), device=device)
+    op.run(d_B, d_C2)
+    op.run(d_B, d_C2)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C2.cpu().numpy()), bits(exp)) and op.get_option("graph_captures") == 2 and op.get_option("graph_replays") == 7
+    # a row range (the multi-GPU driver's panels) and pitched buffers: their own tuple
+    d_Cw = torch.full((6000, 80), float("nan"), device=device)
+    op.run_rows(d_B, 64, d_Cw, 80, 1000, 5000)
+    torch.cuda.synchronize()
+    got = d_Cw.cpu().numpy()
+    assert np.array_equal(bits(got[1000:5000, :64]), bits(exp[1000:5000])) and np.isnan(got[:1000]).all() and np.isnan(got[5000:]).all() and np.isnan(got[:, 64:]).all()
+    assert op.get_option("graph_captures") == 3
+    # the caller captures run() into a graph of its own: plain launches, no nested graph launch
+    replays = op.get_option("graph_replays")
+    g = torch.cuda.CUDAGraph()
+    d_C.fill_(float("nan"))
+    with torch.cuda.graph(g):
+        op.run(d_B, d_C)
+    d_C.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)) and op.get_option("graph_replays") == replays
+    # an option change drops the graph; the plain path still works; preprocess captures again
+    op.set_option("use_graph", 0)
+    assert op.get_option("graph_ready") == 0
+    d_C.fill_(float("nan"))
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)) and op.get_option("graph_replays") == replays
+    # a graph-less handle and a graphed one agree on a small plain graph too (rows kernel only)
+    C1, op1 = run_spmm(device, ptr[:101], idx[:ptr[100]], vals[:ptr[100]], B, options={"use_graph": 1})
+    assert np.array_equal(bits(C1), bits(oracle.spmm_omp(ptr[:101], idx[:ptr[100]], vals[:ptr[100]], B))) and op1.get_option("graph_replays") == 1
+
+
 def test_rmat_and_banded_structures(device, oracle):
     """Hub-dominated (R-MAT) and locality-rich (banded) graphs: every row bit-exact by default (hubs through the hub
     kernel); with "split_long_rows" the hubs follow the documented piece order."""
