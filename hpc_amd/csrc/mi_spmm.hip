@@ -41,6 +41,8 @@ struct mi_spmm_handle {
     int64_t hub_overlap;  // 1 (default): the hub kernel and the segment kernel run on handle-owned side streams, forked from and joined
                           // back into the caller's stream inside every run call (their longest rows then overlap the rows kernel)
     hipStream_t side[2];  // [0]: hub kernel, [1]: segment (+ reduce) kernels; created by the first preprocess that needs them
+    int64_t side_priority; // bit 0: the hub stream is a high-priority stream, bit 1: the segment stream is
+    int64_t segment_overlap; // 1: the segment kernel may go to side stream 1; 0: it stays on the caller's stream, in front of the rows kernel
     hipEvent_t ev_fork, ev_join[2];
     bool fork_recorded, forked[2];   // state of the current run_rows call
     bool overlap_on[2];   // resolved by preprocess: is the fork/join (~20 us of launch latency per call) worth it for this class
@@ -90,6 +92,7 @@ struct mi_spmm_handle {
     hipStream_t gstream;
     hipGraphExec_t gexec;
     struct GraphKey { const float *vin; float *vout; int64_t ldb, ldc; int32_t r0, r1, n_extra; float *extra[kMaxPeerOut]; } gkey;
+    std::vector<int32_t> *hub_rows_sorted;   // host copy of the hub rows, ascending (null: unknown -> every call launches the hub kernel)
     bool gfailed;               // capture or instantiation failed once for this plan: run() launches directly from then on
     int32_t glaunches;          // kernel launches inside the captured set
     int64_t graph_replays, graph_captures;
@@ -127,6 +130,8 @@ static void free_plan(mi_spmm_handle *h)
     h->d_long = nullptr;
     h->d_partials = nullptr;
     h->n_chunks = h->n_long = h->n_medium = h->n_slots = 0;
+    delete h->hub_rows_sorted;
+    h->hub_rows_sorted = nullptr;
     h->local_pct = -1;
     h->ws_bytes = 0;
     h->prepared = false;
@@ -300,6 +305,30 @@ static int build_block_items(mi_spmm_handle *h)
     return MI_SPMM_OK;
 }
 
+// Host copy of the hub rows in row order: a run_rows call (a row panel of the multi-GPU step) whose range holds no hub row
+// skips the hub launch and its side-stream fork (~20 us) instead of launching a grid whose workgroups all leave at once.
+static int note_hub_rows(mi_spmm_handle *h)
+{
+    delete h->hub_rows_sorted;
+    h->hub_rows_sorted = nullptr;
+    if (h->n_long <= 0 || h->split_long || h->n_long > (1 << 16)) return MI_SPMM_OK;
+    std::vector<LongRow> lr((size_t)h->n_long);
+    HIP_TRY(hipMemcpy(lr.data(), h->d_long, lr.size() * sizeof(LongRow), hipMemcpyDeviceToHost));
+    h->hub_rows_sorted = new (std::nothrow) std::vector<int32_t>();
+    if (!h->hub_rows_sorted) return MI_SPMM_ENOMEM;
+    h->hub_rows_sorted->reserve(lr.size());
+    for (const LongRow &r : lr) h->hub_rows_sorted->push_back(r.row);
+    std::sort(h->hub_rows_sorted->begin(), h->hub_rows_sorted->end());
+    return MI_SPMM_OK;
+}
+
+static bool range_has_hub(const mi_spmm_handle *h, int32_t row_begin, int32_t row_end)
+{
+    if (!h->hub_rows_sorted) return true;
+    const auto it = std::lower_bound(h->hub_rows_sorted->begin(), h->hub_rows_sorted->end(), row_begin);
+    return it != h->hub_rows_sorted->end() && *it < row_end;
+}
+
 // The hub kernel's longest row is the step's longest dependent chain; on a side stream it runs beside the rows kernel
 // instead of in front of it.  The stream and its two events belong to the handle (created once, here, never in run()).
 static int ensure_side_streams(mi_spmm_handle *h)
@@ -311,12 +340,12 @@ static int ensure_side_streams(mi_spmm_handle *h)
     const bool long_step = bytes / 6e12 >= 200e-6;
     const bool exact_hubs = h->n_long > 0 && !h->split_long;
     h->overlap_on[0] = exact_hubs && (h->hub_overlap == 2 || (h->hub_overlap == 1 && (long_step || h->max_row_nnz >= 7000)));
-    h->overlap_on[1] = h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
+    h->overlap_on[1] = h->segment_overlap && h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
     if (!(h->overlap_on[0] || h->overlap_on[1]) || h->side[0]) return MI_SPMM_OK;
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, ((h->side_priority >> i) & 1) ? hi : 0));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -410,7 +439,8 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     }
     lap(4);
     {
-        const int src = ensure_side_streams(h);
+        int src = ensure_side_streams(h);
+        if (src == 0) src = note_hub_rows(h);
         if (src != 0) { free_plan(h); return src; }
     }
     h->prepared = true;
@@ -472,6 +502,8 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->split_long = 0;     // every row one chain in stored order (the reference's definition, spmm_ref.cu:10-14)
     h->hub_slice = 0;
     h->hub_overlap = 1;
+    h->side_priority = 3;
+    h->segment_overlap = 0;   // round 4: the segment kernel stays on the caller's stream (see "segment_overlap" in include/mi_spmm.h)
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
     h->xcd_remap = -1;     // auto (see run)
@@ -533,6 +565,19 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
     else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
     else if (k == "hub_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->hub_overlap = v; free_plan(h); }
+    else if (k == "segment_overlap") { h->segment_overlap = v ? 1 : 0; free_plan(h); }
+    else if (k == "side_priority") {
+        if (v < 0 || v > 3) return MI_SPMM_EINVAL;
+        if (v != h->side_priority) {          // the streams are made by the next preprocess
+            for (int i = 0; i < 2; ++i) {
+                if (h->side[i]) { (void)hipStreamSynchronize(h->side[i]); (void)hipStreamDestroy(h->side[i]); h->side[i] = nullptr; }
+                if (h->ev_join[i]) { (void)hipEventDestroy(h->ev_join[i]); h->ev_join[i] = nullptr; }
+            }
+            if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
+        }
+        h->side_priority = v;
+        free_plan(h);
+    }
     else if (k == "long_row_chunk") { if (v < 1 || v > kMaxLongChunk) return MI_SPMM_EINVAL; h->long_chunk = v; free_plan(h); }
     else if (k == "rows_per_block") { if (v < 0 || v > (1 << 20)) return MI_SPMM_EINVAL; h->rows_per_block = v; }
     else if (k == "xcd_remap") h->xcd_remap = v < 0 ? -1 : (v ? 1 : 0);
@@ -570,6 +615,8 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "split_long_rows") *value = h->split_long;
     else if (k == "hub_slice") *value = h->hub_slice;
     else if (k == "hub_overlap") *value = h->hub_overlap;
+    else if (k == "side_priority") *value = h->side_priority;
+    else if (k == "segment_overlap") *value = h->segment_overlap;
     else if (k == "n_hub_rows") *value = h->split_long ? 0 : h->n_long;
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
@@ -824,7 +871,8 @@ static int preprocess_plan(mi_spmm_handle *h)
     }
     lap(4, tp);
     {
-        const int src = ensure_side_streams(h);
+        int src = ensure_side_streams(h);
+        if (src == 0) src = note_hub_rows(h);
         if (src != 0) { free_plan(h); return src; }
     }
     h->prepared = true;
@@ -1014,7 +1062,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     // segment, hub, block and reduce kernels walk their whole tables and keep the rows of this call's range.
     // The hub kernel goes first (its longest row is the step's longest dependent chain) and, like the block kernel,
     // addresses the full width: it is launched with the first column part only.
-    if (h->n_long > 0 && !h->split_long && launch_blocks_here) {
+    if (h->n_long > 0 && !h->split_long && launch_blocks_here && range_has_hub(h, row_begin, row_end)) {
         HubArgs ha{};
         ha.rows = h->d_long;
         ha.row_ptr = h->d_ptr;

@@ -187,6 +187,17 @@ int step_barrier(mi_spmm_dist *d, hipStream_t s, hipStream_t also)
     return 0;
 }
 
+// The barriers of a peer_store / peer2d step ("nobody still reads the C I am about to store into", "every store has landed"):
+// the communicator's all-reduce; without one, the host's barrier callback when one is registered (so an in-process or
+// shared-GPU driver synchronises itself); only with neither does "external_barrier" apply -- the caller has promised to
+// bracket every step -- and without that promise step() has already refused.
+int peer_barrier(mi_spmm_dist *d, hipStream_t s, hipStream_t also)
+{
+    if (d->comm) return device_barrier(d, s);
+    if (d->host_barrier) return step_barrier(d, s, also);
+    return d->external_barrier ? 0 : MI_SPMM_ESTATE;
+}
+
 void close_peers(mi_spmm_dist *d)
 {
     for (void *b : d->peer_base)
@@ -232,7 +243,7 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
         // the two device-side barriers of a peer2d step are all-reduces on the communicator: without one, ranks would push
         // into C_full buffers that may still be read, and nobody would know when the pushes have landed -- refuse, unless
         // the caller has said that it brackets every step with a cross-rank barrier of its own ("external_barrier")
-        if (do_exchange && d->world > 1 && !d->comm && !d->external_barrier) return MI_SPMM_ESTATE;
+        if (do_exchange && d->world > 1 && !d->comm && !d->host_barrier && !d->external_barrier) return MI_SPMM_ESTATE;
     } else if (d->exchange == kIpcPull) {
         if ((int)d->peer_stage.size() != 2 * d->world) return MI_SPMM_ESTATE;
         if (d->world > 1 && !d->comm && !d->host_barrier) return MI_SPMM_ESTATE;
@@ -252,7 +263,7 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
             for (int q = 0; q < d->world; ++q)
                 if (q != d->rank) extra[n_extra++] = d->peer_C[(size_t)q] + (size_t)d->rank * (size_t)n_loc;
         if (do_exchange) {
-            MI_TRY(device_barrier(d, d->s_comm));                   // nobody still reads the C_full we are about to store into
+            MI_TRY(peer_barrier(d, d->s_comm, main));               // nobody still reads the C_full we are about to store into
             HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));
             HIP_TRY(hipStreamWaitEvent(main, d->ev_gathered[0], 0));
         }
@@ -260,7 +271,7 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
         if (do_exchange) {
             HIP_TRY(hipEventRecord(d->ev_computed[0], main));
             HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_computed[0], 0));
-            MI_TRY(device_barrier(d, d->s_comm));                   // every rank's stores have landed (a finished kernel's stores are visible)
+            MI_TRY(peer_barrier(d, d->s_comm, main));               // every rank's stores have landed (a finished kernel's stores are visible)
             HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));
             HIP_TRY(hipStreamWaitEvent(main, d->ev_gathered[0], 0));
         }
@@ -269,7 +280,7 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
     if (d->exchange == kPeer2D) {
         MI_TRY(ensure_push_streams(d));
         // nobody may still be consuming the C_full we are about to overwrite remotely
-        if (do_exchange) MI_TRY(device_barrier(d, d->s_comm));
+        if (do_exchange) MI_TRY(peer_barrier(d, d->s_comm, main));
         HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));     // reused as "step may start pushing"
         for (hipStream_t s : d->s_push) HIP_TRY(hipStreamWaitEvent(s, d->ev_gathered[0], 0));
         float *own = d_C_full + (size_t)d->rank * (size_t)n_loc;
@@ -292,7 +303,7 @@ int step(mi_spmm_dist *d, const float *d_B_loc, float *d_C_full, hipStream_t mai
                 HIP_TRY(hipEventRecord(d->ev_pushed[i], d->s_push[i]));
                 HIP_TRY(hipStreamWaitEvent(d->s_comm, d->ev_pushed[i], 0));
             }
-            MI_TRY(device_barrier(d, d->s_comm));                   // every rank's pushes have landed
+            MI_TRY(peer_barrier(d, d->s_comm, main));               // every rank's pushes have landed
             HIP_TRY(hipEventRecord(d->ev_gathered[0], d->s_comm));
             HIP_TRY(hipStreamWaitEvent(main, d->ev_gathered[0], 0));
         }

@@ -10,14 +10,19 @@
 // fma chain over the row's nonzeros in stored order starting from +0.0f --
 // exactly spmm_ref.cu:10-14 under the reference's fmad build.
 //
-//   spmm_rows_v2     short rows; a lane group per row, lanes own output columns, no cross-lane
-//                    reduction -> bit-identical to the reference kernel   
-//   spmm_chunks      medium rows as ONE exact segment each (straight to C) and hub rows as pieces
-//   spmm_reduce_chunks   ... whose partial sums are added left to right (deterministic; the only
-//                    place where the summation order differs from the reference)   (4.2)
-//   detect_row_blocks + spmm_blocks   16-row groups sharing a column list: B rows staged once per
-//                    group through wave-private LDS, v_mfma_f32_16x16x4_f32 (exact f32) (4.3)
-//   csr_check_cols, compare_kernel (valid.cu), fill_normal_kernel (data.h allocate), unpack_gathered
+//   spmm_rows_v2         short rows: a lane group per row, lanes own output columns, (col, val) pairs fetched 32 at a time one item
+//                        ahead, 8 B-row gathers in flight, no cross-lane reduction                                  
+//   spmm_chunks          medium rows as ONE exact segment each, stored straight to C (32 gathers in flight per lane group);
+//   spmm_reduce_chunks   ... and, only with the opt-in "split_long_rows", hub rows in pieces whose partial sums are added left to
+//                        right (deterministic; the one place where the summation order differs from the reference)      (4.2)
+//   spmm_hub             hub rows in STORED ORDER: per (row, column slice) one chain wave fed through an LDS ring by three loader
+//                        waves; the chain loop is hub_chain_asm.inc (gen_hub_chain.py): one v_fmac_f32 per nonzero, a values via DPP (4.2)
+//   detect_row_blocks, analyze_group_runs, spmm_block_items   16-row groups sharing a column list: pieces (column runs), passes and
+//                        items of up to two pieces sharing their B rows; B and A go global -> VGPR -> v_mfma_f32_16x16x4_f32 with no
+//                        LDS at all; a later pass continues the fma chains through C (exact f32)                              (4.3)
+//   csr_check_cols, compare_kernel (valid.cu), fill_normal_kernel (data.h allocate), unpack_gathered                      (4.4)
+// Every path gives the reference kernel's bits (default options); every store goes through store_c_all / the block epilogue, which
+// also serve the multi-GPU "peer_store" exchange (PeerOut).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -430,14 +435,18 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a
 //     registers (L x U x 8 KiB in flight per workgroup), and writes them to the LDS ring TRANSPOSED -- four loads of one
 //     lane are nonzeros k..k+3 of the same four columns, so a 4 x 4 register transpose (free: register naming) turns
 //     them into one ds_write_b128 per column: ring[column][k..k+3];
-//   * the chain wave owns one column per lane: ONE ds_read_b128 brings its next four B values, one broadcast
-//     ds_read_b128 the four a values: 0.5 LDS reads and one v_fma_f32 per nonzero, k ascending -- the same chain,
-//     bit for bit, as spmm_ref.cu:10-14;
-//   * hand-off through two kinds of LDS words: published[w] = stages loader w has written (loader -> chain wave) and done = stages consumed
-//     (chain wave -> loaders, so a slot is not overwritten early).  A wave's LDS operations execute in order, so a
-//     flag written after the data is seen after the data; no barrier inside the loop, one at kernel start.
-// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free, and so are the loaders'
-// writes with the lane -> (part, group) mapping below.
+//   * the chain wave owns one column per lane: ONE ds_read_b128 brings its next four B values; a stage's 64 a values arrive
+//     with a single ds_read_b128 -- lane i of every 16-lane row holds a[4 i .. 4 i + 3] -- and link 4 i + r takes its factor
+//     out of register r of row lane i through DPP (v_fmac_f32_dpp ... row_newbcast:i): 17 LDS reads and 64 fmacs per stage,
+//     k ascending -- the same chain, bit for bit, as spmm_ref.cu:10-14 (round 3: 16 broadcast reads for the a values; the
+//     wave is bound by its own instruction issue, ~5 cycles per instruction whatever it is: 107 -> 88 instructions per stage);
+//   * hand-off through two LDS words: pub = stages published so far, IN ORDER (a loader publishes stage s once pub == s; the
+//     row's last stage writes INT_MAX), so that one poll tells the chain wave it may fetch the next TWO stages; done = stages
+//     consumed (chain wave -> loaders, so a slot is not overwritten early), written once per pair of stages.  A wave's LDS
+//     operations execute in order, so a flag written after the data is seen after the data; no barrier inside the loop, one
+//     at kernel start.
+// Column stride in the ring: 68 floats (64 + 4): the chain wave's 16-byte reads are conflict-free (ds_read_b128: 16-lane
+// groups over 64 banks: SQ_LDS_BANK_CONFLICT = 0 for them alone); the loaders' transposed writes follow the lane -> (part, group) mapping below.
 #include "hub_chain_asm.inc"
 struct HubArgs {
     const LongRow *rows;     // hub rows, longest first
@@ -548,17 +557,16 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 
     // ---- loaders: wave w takes stages w, w + L, w + 2L, ...
     const int w = wave - 1;
-    // Lane -> (16-byte part of the row slice, nonzero group).  In publish() a lane's write for (e, h) starts at 16-byte
-    // granule (4 part + e) (CS / 4) + g + NG h = 4 part + g + const (mod 8: CS / 4 = 17), and the LDS serves a
-    // ds_write_b128 EIGHT contiguous lanes at a time over 32 banks = 8 granules (MI355X_MICROARCH.md, LDS): the 8 lanes
-    // of such a group must differ in 4 part + g (mod 8).  So a group is two parts x four nonzero groups (part = lane & 1,
-    // g = (lane >> 1) & 3) and the lane's upper bits select further parts first, then further groups.  Round 3 reasoned
-    // with 16 lanes over 64 banks (four parts x four groups per quarter wave): SQ_LDS_BANK_CONFLICT counted exactly 4
-    // cycles per write for it, 0 for this one (profiles/r04_hub_lds_counters.txt; part = lane % LPS, g = lane / LPS is
-    // 4-way at SW = 32).  Every conflicting write delays the chain wave's reads.  Two consecutive lanes fetch 32
-    // contiguous bytes of one B row, the lane 8 further on the next 32.
-    constexpr int PH = LPS / 2;                                  // parts beyond the first two, in lane bits 3..
-    const int part = (lane & 1) + 2 * ((lane >> 3) % PH), g = ((lane >> 1) & 3) + 4 * ((lane >> 3) / PH);
+    // Lane -> (16-byte part of the row slice, nonzero group): a quarter wave is four parts x four groups (part = lane & 3,
+    // g = (lane >> 2) & 3), the lane's upper bits select further parts first, then further groups; four consecutive lanes
+    // fetch 64 contiguous bytes of one B row.  In publish() a lane's write for (e, h) starts at 16-byte granule
+    // (4 part + e) (CS / 4) + g + NG h: against the plain part = lane % LPS, g = lane / LPS this mapping took the chain wave from
+    // 700 to 622 ticks per stage in round 3.  What the counters say (profiles/r04_hub_lds_counters.txt, r04_hub_experiments.txt):
+    // 64 bank-conflict cycles per stage remain, with this mapping AND with 2 parts x 4 groups per 8 contiguous lanes (the
+    // grouping MI355X_MICROARCH.md gives for ds_write_b128) -- so they are not these writes' (the chain wave's reads: 0 conflicts
+    // alone) but most likely the 16 ds_bpermute column broadcasts of issue(); the LDS is busy 85 of a stage's ~495 cycles.
+    constexpr int PH = LPS / 4;                                  // parts beyond the first four, in lane bits 4..
+    const int part = (lane & 3) + 4 * ((lane >> 4) % PH), g = ((lane >> 2) & 3) + 4 * ((lane >> 4) / PH);
     // A slice that sticks out past N (or a width that is no multiple of 4) shifts its last parts back to column N - 4: they
     // re-fetch and recompute columns of their neighbours with identical bits (as in the rows kernel).
     const int colf = min(slice * SW + 4 * part, a.N - 4);
@@ -948,6 +956,33 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
         // otherwise sinks both refills to the bottom of the loop with all A-operand loads last, and -- loads return in
         // order -- the wait for set 0's A operands at the top then waits for every B load: no overlap.
         // Run items: a trip is a whole batch pair, so set 1's batch always exists; list items: it may be past the end (zeros).
+        // A piece's finished tile: register q of the tiles (x, 0..V-1) leaves as V floats per lane, 16 lanes = one 64V-byte row
+        // segment, four rows per store instruction.  A tile that a later pass continues stays cacheable; a final one is nt.
+        auto store_piece = [&](int j) {
+            int r0 = sg[j] << 4;
+            asm volatile("" : "+s"(r0));   // the row addresses below are computed here, not hoisted above the k loop (registers)
+            const bool carried = (sfl[j] & kPieceCarryOut) != 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = r0 + 4 * kq + q;
+                if (row >= a.row_lo && row < a.row_hi) {
+#pragma unroll
+                    for (int x = 0; x < XC; ++x) {
+                        BV v;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) v[e] = acc[j][V * x + e][q];
+                        const int64_t off = (int64_t)row * a.ldc + colv + CW * x;
+                        if (carried) *reinterpret_cast<BV *>(a.C + off) = v;
+                        else {
+                            __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.C + off));
+#pragma unroll
+                            for (int pq = 0; pq < kMaxPeerOut; ++pq)
+                                if (pq < a.po.n) __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.po.p[pq] + off));
+                        }
+                    }
+                }
+            }
+        };
         int kb = 0;
         if (G >= 2 && np >= 2) {
             // both pieces run up to l1, a whole number of trips, l1 <= L
@@ -964,6 +999,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
                 fetch(R1, a1, cn1, kb + PAIR + KT);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // (Round 4 tried issuing the shorter piece's 4 XC stores HERE, L - l1 rows before the longer piece is done, so that
+            // they drain under the remainder loop: 1.171 -> 1.179-1.183 ms on C4, 221 -> 238 VGPRs.  A third of the two-piece items
+            // are (128, 64) pairs, and a wave that stalls at store issue stalls its MFMAs all the same: profiles/r04_c4_notes.txt.)
         }
         for (; kb < L; kb += PAIR) {
             if (RUN) transpose_a();
@@ -977,36 +1015,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
             fetch(R1, a1, cn1, kb + PAIR + KT);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // Epilogue: register q of the tiles (x, 0..V-1) leaves as V floats per lane, 16 lanes = one 64V-byte row segment,
-        // four rows per store instruction.  A tile that a later pass continues stays cacheable; a final one is nt.
+        // Epilogue: the tiles that have not left yet
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            if (j < np) {
-                int r0 = sg[j] << 4;
-                asm volatile("" : "+s"(r0));   // the row addresses below are computed here, not hoisted above the k loop (registers)
-                const bool carried = (sfl[j] & kPieceCarryOut) != 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = r0 + 4 * kq + q;
-                    if (row >= a.row_lo && row < a.row_hi) {
-#pragma unroll
-                        for (int x = 0; x < XC; ++x) {
-                            BV v;
-#pragma unroll
-                            for (int e = 0; e < V; ++e) v[e] = acc[j][V * x + e][q];
-                            const int64_t off = (int64_t)row * a.ldc + colv + CW * x;
-                            if (carried) *reinterpret_cast<BV *>(a.C + off) = v;
-                            else {
-                                __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.C + off));
-#pragma unroll
-                                for (int pq = 0; pq < kMaxPeerOut; ++pq)
-                                    if (pq < a.po.n) __builtin_nontemporal_store(v, reinterpret_cast<BV *>(a.po.p[pq] + off));
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        for (int j = 0; j < G; ++j)
+            if (j < np) store_piece(j);
     }
 }
 

@@ -132,9 +132,15 @@ const char *mi_spmm_strerror(int code);
  *   "long_row_chunk"      piece length in nonzeros (split mode)
  *   "hub_slice"           columns per hub workgroup: 16, 32, 64; 0 = auto (32; 16 when N <= 16 or when the longest
  *                         row's chain alone is more than half of the step)
- *   "hub_overlap"         1 (default): the hub and segment kernels run on handle-owned side streams forked from and joined
- *                         into the caller's stream inside every run call, when the step is long enough to hide their
- *                         longest rows behind the rows kernel (the fork costs ~20 us); 0: never; 2: always
+ *   "hub_overlap"         1 (default): the hub kernel runs on a handle-owned high-priority side stream forked from and joined
+ *                         into the caller's stream inside every run call (events only), when the step is long enough to hide its
+ *                         longest row behind the rows kernel (the fork costs ~20 us); 0: never; 2: always
+ *   "segment_overlap"     0 (default): the segment kernel stays on the caller's stream, in front of the rows kernel.  1: it goes to
+ *                         a second side stream under the "hub_overlap" rule (rounds 2-3).  Two side streams can land on ONE
+ *                         hardware queue (the runtime maps streams to a few queues per priority): hub and segment kernels then run
+ *                         one after the other and the step is slower than with no side stream at all; with one side stream that
+ *                         cannot happen, and it measured equal or faster on every shape (profiles/r04_side_streams.txt)
+ *   "side_priority"       bit 0 / bit 1: the hub / segment side stream is a high-priority stream (default 3)
  *   "use_graph"           0 (default) / 1: the step's launch set (2-4 kernels plus the side streams' fork and join) is captured once
  *                         into a HIP graph on a handle-owned stream and run() replays it with ONE hipGraphLaunch on the caller's
  *                         stream -- for steps of tens of microseconds (small graphs) the launches are the step.  preprocess captures

@@ -39,9 +39,10 @@
  *                 of a step runs with several real ranks where RCCL cannot (ranks sharing one GPU); not a fast path.
  * 0 and 1 need a communicator (mi_spmm_dist_comm_init); 2 and 3 need the peers' C_full (mi_spmm_dist_set_peers) and,
  * to be self-synchronising, a communicator too (a one-element all-reduce is the end-of-step barrier).  Without a
- * communicator a peer2d step at world > 1 is refused (MI_SPMM_ESTATE) unless "external_barrier" = 1 says that the caller
- * brackets every step with a cross-rank barrier of its own (after the previous step's consumers, and after the
- * step's stream work has completed).
+ * communicator the two barriers go through the host callback of mi_spmm_dist_set_host_barrier when one is registered
+ * (in-process and shared-GPU drivers: the step still synchronises itself); with neither, a peer2d / peer_store step at
+ * world > 1 is refused (MI_SPMM_ESTATE) unless "external_barrier" = 1 says that the caller brackets every step with a
+ * cross-rank barrier of its own (after the previous step's consumers, and after the step's stream work has completed).
  *
  * Errors: 0 = ok; negative MI_SPMM_E* codes of mi_spmm.h; positive hipError_t; ncclResult_t r is returned as
  * MI_SPMM_DIST_ENCCL_BASE - r.  Never aborts.

@@ -19,7 +19,7 @@ rep("void spmm_block_items(BlockArgs a)", "void spmm_block_items_stamped(BlockAr
 rep("    const int lane = threadIdx.x & 63;\n", "    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();\n    const int lane = threadIdx.x & 63;\n")
 rep("    if (n_in == 0) return;\n", "    if (n_in == 0) return;\n    const unsigned long long t_rec = __builtin_amdgcn_s_memtime();\n    unsigned long long t_loop0 = 0, t_loop1 = 0;\n")
 rep("        int kb = 0;\n", "        asm volatile(\"s_waitcnt vmcnt(16)\" ::: \"memory\");\n        t_loop0 = __builtin_amdgcn_s_memtime();\n        int kb = 0;\n")
-rep("        // Epilogue: register q of the tiles (x, 0..V-1) leaves as V floats per lane", "        t_loop1 = __builtin_amdgcn_s_memtime();\n        // Epilogue: register q of the tiles (x, 0..V-1) leaves as V floats per lane")
+rep("        // Epilogue: the tiles that have not left yet\n", "        t_loop1 = __builtin_amdgcn_s_memtime();\n        // Epilogue: the tiles that have not left yet\n")
 idx = k.rindex("}\n")
 k = k[:idx] + ("    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    if (lane == 0) { const unsigned long long t_end = __builtin_amdgcn_s_memtime(); unsigned long long *o = dbg + (size_t)ii * 8;\n"
                "        o[0] = t_rec - t_start; o[1] = t_loop0 - t_rec; o[2] = t_loop1 - t_loop0; o[3] = t_end - t_loop1; o[4] = (unsigned long long)plen[0]; o[5] = (unsigned long long)m; o[6] = r_start; o[7] = __builtin_amdgcn_s_memrealtime(); }\n}\n")

@@ -48,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--lens", default="32,256")
+    ap.add_argument("--skip", default="", help="debugging: comma list of graph,vendor,student (columns left out; their cells read nan)")
     args = ap.parse_args()
     import torch
     from hpc_amd import CSR, SpMMOpt, synth, valid
@@ -56,6 +57,7 @@ def main():
 
     dev = torch.device("cuda:0")
     lens = [int(x) for x in args.lens.split(",")]
+    skip = set(x for x in args.skip.split(",") if x)
     rows_out = {n: [] for n in lens}
     for name, M, nnz_target, max_deg in DATASETS:
         if args.only and args.only not in name:
@@ -75,28 +77,41 @@ def main():
             ours = SpMMOpt(g, N)
             ours.preprocess(d_B, d_C)
             t_ours = timed(lambda: ours.run(d_B, d_C), 3, 10)
-            vend = SpMMRocSparse(g, N)
-            vend.preprocess(d_B, d_V)
-            t_vend = timed(lambda: vend.run(d_B, d_V), 3, 10)
-            bad = valid(d_C, d_V, M * N)
-            ok = oracle.validation_passes(bad, M, N)                      # test_spmm.cu:43 against the vendor result
+            # the same step replayed from the handle's HIP graph ("use_graph" = 1: one hipGraphLaunch instead of 2-4 launches + fork/join)
+            t_graph, same = float("nan"), True
+            if "graph" not in skip:
+                d_G = torch.full((M, N), float("nan"), device=dev)
+                ours_g = SpMMOpt(g, N)
+                ours_g.set_option("use_graph", 1)
+                ours_g.preprocess(d_B, d_G)
+                t_graph = timed(lambda: ours_g.run(d_B, d_G), 3, 10)
+                same = bool(torch.equal(d_G.view(torch.int32), d_C.view(torch.int32))) and ours_g.get_option("graph_replays") == 13
+                del ours_g, d_G
+            vend, t_vend, ok = None, float("nan"), True
+            if "vendor" not in skip:
+                vend = SpMMRocSparse(g, N)
+                vend.preprocess(d_B, d_V)
+                t_vend = timed(lambda: vend.run(d_B, d_V), 3, 10)
+                bad = valid(d_C, d_V, M * N)
+                ok = oracle.validation_passes(bad, M, N)                      # test_spmm.cu:43 against the vendor result
             t_stud = float("nan")
-            if oracle.ref_available():
+            if oracle.ref_available() and "student" not in skip:
                 ro = oracle.RefOpt(d_ptr, d_idx, d_val, M, N)
                 t_stud = timed(lambda: ro.run(d_B, d_V), 1, 3)            # accumulates; timing only
                 del ro
             rows_out[N].append((name, M, nnz, int(deg.max()), t_vend, t_ours, t_vend / t_ours, t_stud, t_stud / t_ours, ok,
-                                ours.get_option("n_hub_rows"), ours.get_option("n_partial_slots"), ours.get_option("long_row_threshold")))
+                                ours.get_option("n_hub_rows"), ours.get_option("n_partial_slots"), ours.get_option("long_row_threshold"),
+                                t_graph, same, ours.get_option("n_launches")))
             del d_B, d_C, d_V, ours, vend
         del d_ptr, d_idx, d_val, g
         torch.cuda.empty_cache()
     print("# Reference-style report table on MI355X (dataset-shaped synthetic graphs; see scripts/report_table.py)\n")
     for N in lens:
         print(f"### `kLen = {N}`\n")
-        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold |")
-        print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | ours with use_graph = 1 (same bits?) | saved by the graph (us) |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
         for r in rows_out[N]:
-            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} |")
+            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[13]:.6g} ({'same' if r[14] else 'DIFFERENT'}) | {(r[5] - r[13]) * 1e6:.1f} |")
         sp = [r[6] for r in rows_out[N]]
         if sp:
             print(f"\nspeed-up over the vendor library: min {min(sp):.2f}, geometric mean {float(np.exp(np.mean(np.log(sp)))):.2f}, max {max(sp):.2f} "

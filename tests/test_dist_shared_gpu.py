@@ -163,6 +163,15 @@ def _native_worker(rank, world, port, M, n_loc, n_panels, kind, exchange, q):
             barrier()                     # nobody still reads the C_full we are about to write into
             sh.run(B_loc, C_full)
             barrier()                     # every rank's pushes have landed
+        if exchange != "ipc_pull":
+            # With a host barrier registered the step synchronises ITSELF (both barriers through the callback): no promise from
+            # the caller needed, no brackets around the steps.  NaN-poison first: the result compared below is this mode's.
+            sh.set_option("external_barrier", 0)
+            sh.set_host_barrier(host_barrier)
+            C_full.fill_(float("nan"))
+            for _ in range(2):
+                sh.run(B_loc, C_full)
+            barrier()
         B_all = torch.from_numpy(np.ascontiguousarray(np.concatenate(blocks, axis=1))).to(dev)
         C_one = torch.empty(M, n_loc * world, device=dev)
         one = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc * world)

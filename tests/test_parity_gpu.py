@@ -174,6 +174,39 @@ def test_hub_kernel_stage_and_ring_boundaries(device, oracle, N):
         assert np.array_equal(bits(C), bits(exp)), (opts, [lens[i] for i in np.nonzero((bits(C) != bits(exp)).any(axis=1))[0]])
 
 
+def test_row_panels_without_hub_rows_skip_the_hub_launch(device, oracle):
+    """run_rows on a range that holds no hub row launches no hub grid (and forks no side stream for it): the handle keeps a
+    row-ordered host copy of the hub list.  The multi-GPU step calls run_rows once per row panel."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    lens = [5] * 400
+    for r in (7, 130, 131):
+        lens[r] = 900
+    K, N = 2000, 64
+    g = np.random.Generator(np.random.Philox(key=[77, 4]))
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = g.integers(0, K, size=int(ptr[-1])).astype(np.int32)
+    vals = synth.normal_f32(idx.size, 78)
+    B = synth.normal_f32(K * N, 79).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    for overlap in (0, 2):
+        d_C = torch.full((400, N), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(400, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+        op.set_option("long_row_threshold", 256)
+        op.set_option("hub_overlap", overlap)
+        op.preprocess(d_B, d_C)
+        assert op.get_option("n_hub_rows") == 3 and op.get_option("n_chunks") == 0
+        launches = {}
+        for r0, r1 in ((0, 7), (7, 8), (8, 130), (130, 132), (132, 400)):
+            op.run_rows(d_B, N, d_C, N, r0, r1)
+            launches[(r0, r1)] = op.get_option("n_launches")
+        torch.cuda.synchronize()
+        assert launches == {(0, 7): 1, (7, 8): 2, (8, 130): 1, (130, 132): 2, (132, 400): 1}, launches
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+
+
 def test_hub_rows_of_random_lengths(device, oracle):
     """Seeded random hub lengths (0 .. 30 000, with the multiples of the 64-nonzero stage and of the six-slot ring over-represented),
     random widths and slice widths, row-range calls: the chain wave's assembly loop (hub_chain_asm.inc) enters, wraps and leaves its
@@ -203,7 +236,7 @@ def test_hub_rows_of_random_lengths(device, oracle):
         B = synth.normal_f32(K * N, 6600 + case).reshape(K, N)
         exp = oracle.spmm_omp(ptr, idx, vals, B)
         M = len(lens)
-        opts = {"long_row_threshold": int(g.choice([30, 64, 200])), "medium_row_threshold": 8, "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3]}
+        opts = {"long_row_threshold": int(g.choice([30, 64, 200])), "medium_row_threshold": 8, "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3], "segment_overlap": case % 2}
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
         d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
@@ -893,7 +926,8 @@ def test_run_is_graph_capturable_and_stream_ordered(device, oracle, split, overl
     op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
     op.set_option("long_row_threshold", 512)
     op.set_option("split_long_rows", split)
-    op.set_option("hub_overlap", overlap)      # 2: hub and segment kernels on the handle's side streams, forked and joined inside run()
+    op.set_option("hub_overlap", overlap)      # 2: hub (and, with "segment_overlap", segment) kernels on the handle's side streams, forked and joined inside run()
+    op.set_option("segment_overlap", 1 if overlap == 2 else 0)
     op.preprocess(d_B, d_C)
     exp = expected(oracle, ptr, idx, vals, B, split, 512, 256)
     side = torch.cuda.Stream(device=device)
@@ -935,6 +969,7 @@ def test_use_graph_replays_the_captured_launch_set(device, oracle, overlap):
     op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
     op.set_option("long_row_threshold", 512)
     op.set_option("hub_overlap", overlap)
+    op.set_option("segment_overlap", 1 if overlap == 2 else 0)      # both side streams become branches of the graph
     op.set_option("use_graph", 1)
     assert op.get_option("use_graph") == 1 and op.get_option("graph_ready") == 0
     op.preprocess(d_B, d_C)
@@ -1040,7 +1075,7 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
         opts = {"medium_row_threshold": int(g.choice([0, 1, 5, 64, 1000])),
                 "long_row_threshold": int(g.choice([6, 40, 2048])), "long_row_chunk": int(g.choice([3, 16, 256])),
                 "block_path": int(g.choice([0, 1])), "segment_unroll": int(g.choice([8, 16, 32])), "split_long_rows": int(case % 3 == 2),
-                "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3]}
+                "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3], "segment_overlap": (case // 3) % 2}
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
         d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
