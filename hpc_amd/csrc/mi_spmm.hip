@@ -92,13 +92,6 @@ struct mi_spmm_handle {
     hipStream_t gstream;
     hipGraphExec_t gexec;
     struct GraphKey { const float *vin; float *vout; int64_t ldb, ldc; int32_t r0, r1, n_extra; float *extra[kMaxPeerOut]; } gkey;
-    // "block_lds" (round 4 experiment): the run items of a pass grouped into workgroups of <= 2 items with one first column
-    int64_t block_lds;
-    int32_t *d_blk_wg;          // wg_first arrays of all passes, one after the other
-    size_t blk_wg_cap;
-    struct { int32_t off, n; } blk_wg[kMaxPieces];   // [pass]: where its wg_first array starts in d_blk_wg, workgroups
-    unsigned int *d_blk_err;
-    int64_t blk_dbg_ptr;        // EXPERIMENT: device buffer for spmm_block_lds' stamps (caller-owned; 0 = none); pass p's workgroups at + blk_wg[p].off * 64
     std::vector<int32_t> *hub_rows_sorted;   // host copy of the hub rows, ascending (null: unknown -> every call launches the hub kernel)
     bool gfailed;               // capture or instantiation failed once for this plan: run() launches directly from then on
     int32_t glaunches;          // kernel launches inside the captured set
@@ -130,7 +123,6 @@ static void free_plan(mi_spmm_handle *h)
     if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
     h->n_blk_items = h->n_blk_pieces = h->n_blk_passes = h->n_blk_shared_items = 0;
     std::memset(h->blk_launch, 0, sizeof(h->blk_launch));
-    std::memset(h->blk_wg, 0, sizeof(h->blk_wg));
     h->d_blk_flag = nullptr;
     h->d_blk_groups = nullptr;
     h->n_blk_groups = 0;
@@ -313,44 +305,6 @@ static int build_block_items(mi_spmm_handle *h)
     return MI_SPMM_OK;
 }
 
-// "block_lds": group every pass's run items (class 2 of the launch table: column-ordered) into workgroups of at most two items
-// = four pieces that start at the same column.  Experiment-grade: the item list comes back to the host (3.6 MB on C4).
-static int build_block_lds_table(mi_spmm_handle *h)
-{
-    std::memset(h->blk_wg, 0, sizeof(h->blk_wg));
-    if (!h->block_lds || h->n_blk_items <= 0 || h->feat != 256) return MI_SPMM_OK;
-    std::vector<BlockItem> items((size_t)h->n_blk_items);
-    HIP_TRY(hipMemcpy(items.data(), h->d_blk_items, items.size() * sizeof(BlockItem), hipMemcpyDeviceToHost));
-    std::vector<int32_t> wg;
-    for (int pass = 0; pass < h->n_blk_passes; ++pass) {
-        const int32_t off = h->blk_launch[pass][2].off, n = h->blk_launch[pass][2].n;
-        if (n <= 0) continue;
-        h->blk_wg[pass].off = (int32_t)wg.size();
-        int32_t i = 0, nw = 0;
-        while (i < n) {
-            wg.push_back(i);
-            ++nw;
-            const int32_t c0 = items[(size_t)(off + i)].c0;
-            i += (i + 1 < n && items[(size_t)(off + i + 1)].c0 == c0) ? 2 : 1;
-        }
-        wg.push_back(n);
-        h->blk_wg[pass].n = nw;
-    }
-    if (wg.empty()) return MI_SPMM_OK;
-    if (h->blk_wg_cap < wg.size()) {
-        if (h->d_blk_wg) (void)hipFree(h->d_blk_wg);
-        h->d_blk_wg = nullptr;
-        if (hipMalloc((void **)&h->d_blk_wg, wg.size() * sizeof(int32_t)) != hipSuccess) return MI_SPMM_ENOMEM;
-        h->blk_wg_cap = wg.size();
-    }
-    HIP_TRY(hipMemcpy(h->d_blk_wg, wg.data(), wg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (!h->d_blk_err) {
-        if (hipMalloc((void **)&h->d_blk_err, 256) != hipSuccess) return MI_SPMM_ENOMEM;
-        HIP_TRY(hipMemset(h->d_blk_err, 0, 256));
-    }
-    return MI_SPMM_OK;
-}
-
 // Host copy of the hub rows in row order: a run_rows call (a row panel of the multi-GPU step) whose range holds no hub row
 // skips the hub launch and its side-stream fork (~20 us) instead of launching a grid whose workgroups all leave at once.
 static int note_hub_rows(mi_spmm_handle *h)
@@ -487,7 +441,6 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     {
         int src = ensure_side_streams(h);
         if (src == 0) src = note_hub_rows(h);
-        if (src == 0) src = build_block_lds_table(h);
         if (src != 0) { free_plan(h); return src; }
     }
     h->prepared = true;
@@ -590,8 +543,6 @@ int mi_spmm_destroy(mi_spmm_handle *h)
     scratch_release(&h->scratch_b);
     if (h->d_col_bad) (void)hipFree(h->d_col_bad);
     if (h->d_blk_items) (void)hipFree(h->d_blk_items);
-    if (h->d_blk_wg) (void)hipFree(h->d_blk_wg);
-    if (h->d_blk_err) (void)hipFree(h->d_blk_err);
     for (int i = 0; i < 2; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -647,8 +598,6 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "block_share") { if (v < 1 || v > kMaxShare) return MI_SPMM_EINVAL; h->block_share = v; free_plan(h); }
     else if (k == "block_max_pieces") { if (v < 1 || v > kMaxPieces) return MI_SPMM_EINVAL; h->block_max_pieces = v; free_plan(h); }
     else if (k == "block_wg_waves") { if (v != 1 && v != 2 && v != 4) return MI_SPMM_EINVAL; h->block_wg_waves = v; }
-    else if (k == "block_lds") { h->block_lds = v ? 1 : 0; free_plan(h); }
-    else if (k == "block_lds_dbg_ptr") h->blk_dbg_ptr = v;
     else if (k == "block_run_min") { if (v < 1) return MI_SPMM_EINVAL; h->block_run_min = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
@@ -698,13 +647,6 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "block_max_pieces") *value = h->block_max_pieces;
     else if (k == "block_run_min") *value = h->block_run_min;
     else if (k == "block_wg_waves") *value = h->block_wg_waves;
-    else if (k == "block_lds") *value = h->block_lds;
-    else if (k == "n_block_lds_workgroups") { *value = 0; for (int p = 0; p < kMaxPieces; ++p) *value += h->blk_wg[p].n; }
-    else if (k == "block_lds_error") {
-        unsigned int e = 0;
-        if (h->d_blk_err && hipMemcpy(&e, h->d_blk_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) e = 0xffffffffu;
-        *value = e;
-    }
     else if (k == "n_block_items") *value = h->n_blk_items;
     else if (k == "n_block_pieces") *value = h->n_blk_pieces;
     else if (k == "n_block_passes") *value = h->n_blk_passes;
@@ -931,7 +873,6 @@ static int preprocess_plan(mi_spmm_handle *h)
     {
         int src = ensure_side_streams(h);
         if (src == 0) src = note_hub_rows(h);
-        if (src == 0) src = build_block_lds_table(h);
         if (src != 0) { free_plan(h); return src; }
     }
     h->prepared = true;
@@ -1221,24 +1162,6 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
                 // one item per wave, and ONE wave per workgroup by default: items differ 4x in length (64 or 128 rows, one or two
                 // pieces), and a 4-wave workgroup holds its four wave slots until its longest item is done -- 1.38 of 2 possible
                 // waves per SIMD were resident against 1.80 with single-wave workgroups (profiles/r03_c4_item_timeline.txt)
-                if (cls == 2 && h->blk_wg[pass].n > 0 && !wide_full && full.N == 256 && row_begin == 0 && row_end == M && po_full.n == 0) {
-                    // "block_lds": one workgroup per first column, B rows through an LDS ring (spmm_kernels.hpp spmm_block_lds)
-                    BlockLdsArgs la{};
-                    la.items = ba.items;
-                    la.wg_first = h->d_blk_wg + h->blk_wg[pass].off;
-                    la.vals = h->d_val;
-                    la.B = full.B;
-                    la.C = full.C;
-                    la.ldb = ldb;
-                    la.ldc = ldc;
-                    la.n_wg = h->blk_wg[pass].n;
-                    la.remap = ba.remap;
-                    la.err = h->d_blk_err;
-                    la.dbg = h->blk_dbg_ptr ? reinterpret_cast<unsigned long long *>(h->blk_dbg_ptr) + (size_t)h->blk_wg[pass].off * 64 : nullptr;
-                    hipLaunchKernelGGL(spmm_block_lds, dim3((unsigned)la.n_wg), dim3(BlockLdsCfg::THREADS), 0, s, la);
-                    ++launches;
-                    continue;
-                }
                 const int wpw = (int)h->block_wg_waves;
                 dim3 bgrid((unsigned)((n + wpw - 1) / wpw), slabs);
                 launch_block_items(slab, cls, wide_full, ba, bgrid, s, 64 * wpw);

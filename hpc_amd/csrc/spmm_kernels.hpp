@@ -1023,262 +1023,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
 }
 
 
-// ---- block path, LDS-fed variant (round 4 experiment, option "block_lds"): one workgroup per START COLUMN --------------------
-// spmm_block_items brings every B row through the CU's vector-memory path once per ITEM (<= 2 pieces): 128 B of B per MFMA,
-// and that path -- ~22 B/clk per CU under this kernel's mix -- is what its k loop runs at.  Here the run items that
-// start at the same column (consecutive in the column-ordered item list) form one workgroup of up to NC = 4 pieces: ONE loader
-// wave brings the B rows c0, c0+1, ... into an LDS ring by LDS-DMA (global_load_lds_dwordx4: one instruction = one 256-column
-// row = 1 KiB, lane-linear, no VGPRs), 16 rows per stage, and up to four consumer waves -- one piece each, 64 accumulator
-// registers -- read their MFMA B operands out of the ring with ds_read_b128 in operand shape (lane (kq, i16): row 4 s + kq,
-// columns 64 x + 4 i16 .. +3: conflict-free, MI355X_MICROARCH.md LDS table).  B crosses the L1 path once per workgroup.
-// No barrier after the first: hand-off through LDS words as in spmm_hub (pub: stages landed; done[w]: stages consumer w has
-// read).  The arithmetic is spmm_block_items': the same f32 MFMA chains, k ascending, A operands by 16-byte loads + 4 x 4
-// permlane transpose, carried tiles continued through C.
-struct BlockLdsArgs {
-    const BlockItem *items;      // the pass's run items, column-ordered
-    const int32_t *wg_first;     // [n_wg + 1] first item of every workgroup's range (<= 2 items = <= 4 pieces, one first column)
-    const float *vals;
-    const float *B;
-    float *C;
-    int64_t ldb;
-    int64_t ldc;
-    int32_t n_wg;
-    int32_t remap;
-    unsigned int *err;           // set when a bounded spin gives up (development guard: a hang would cost a GPU box)
-    unsigned long long *dbg;     // EXPERIMENT: s_memtime stamps, 8 per wave, 8 waves per workgroup (null: none)
-};
-
-__device__ __forceinline__ bool lane_is0() { return (threadIdx.x & 63) == 0; }
-
-struct BlockLdsCfg {
-    static constexpr int NC = 4;             // consumer waves = pieces per workgroup
-    static constexpr int NS = 3;             // ring slots: the stage being read + D in flight.  3 x 20 KiB = 60 KiB: TWO workgroups per CU
-    static constexpr int NL = 2;             // loader waves: an LDS-DMA instruction costs its wave ~140 cycles; 20 per stage is more than one wave can issue
-    static constexpr int SR = 16;            // B rows per stage
-    static constexpr int D = 2;              // stages the loader keeps in flight behind the newest published one
-    static constexpr int A_FLOATS = NC * 256;          // the stage's A operands: per piece 16 rows x 16 values, lane-linear as the DMA leaves them
-    static constexpr int SLOT_FLOATS = SR * 256 + A_FLOATS;
-    static constexpr int DMA_PER_STAGE = (SR + NC) / NL;   // per loader wave
-    static constexpr int THREADS = 64 * (NC + NL);
-    static constexpr int SPIN_LIMIT = 1 << 24;
-};
-
-__global__ __launch_bounds__(BlockLdsCfg::THREADS, 2) void spmm_block_lds(BlockLdsArgs a)
-{
-    typedef BlockLdsCfg K;
-    __shared__ __attribute__((aligned(16))) float ring[K::NS * K::SLOT_FLOATS];      // 60 KiB: two workgroups per CU
-    __shared__ int flags[8];                                                          // [0], [1] pub of loader 0 / 1 (stages landed), [4 + w] done[w]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int wg = a.remap ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-    unsigned long long *dw = a.dbg ? a.dbg + ((size_t)wg * 8 + (threadIdx.x >> 6)) * 8 : nullptr;
-    auto stamp = [&](int i, unsigned long long v) { if (dw && lane_is0()) dw[i] = v; };
-    const int i0 = a.wg_first[wg], i1 = a.wg_first[wg + 1];
-    // the (<= 2) item records: lanes 0-15 the first, lanes 16-31 the second (or the first again)
-    const int32_t rec = reinterpret_cast<const int32_t *>(a.items + (i0 + ((lane >> 4) & 1 && i0 + 1 < i1 ? 1 : 0)))[lane & 15];
-    const int m0 = __builtin_amdgcn_readlane(rec, 0);
-    const int m1 = (i0 + 1 < i1) ? __builtin_amdgcn_readlane(rec, 16) : 0;
-    const int c0 = __builtin_amdgcn_readlane(rec, 1);
-    const int np = m0 + m1;                                                           // pieces of this workgroup (1..4)
-    int lmax = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int it = q >> 1, j = q & 1;
-        const int len = __builtin_amdgcn_readlane(rec, 16 * it + 4 + 6 * j);
-        const bool used = it == 0 ? j < m0 : j < m1;
-        lmax = (used && len > lmax) ? len : lmax;
-    }
-    const int nst_all = lmax / K::SR;                                                 // run pieces are whole numbers of 16-row stages
-    if (threadIdx.x < 8) flags[threadIdx.x] = (threadIdx.x >= 4 && (int)threadIdx.x - 4 >= np) ? 0x7fffffff : 0;
-    __syncthreads();
-    stamp(0, st0);
-    stamp(1, __builtin_amdgcn_s_memtime());
-
-    if (wave >= K::NC) {
-        const int lj = wave - K::NC;                                                  // loader lj: B rows lj, lj + 2, ... of every stage, A operands of pieces lj, lj + 2
-        unsigned long long w_slot = 0, w_vm = 0, t_first = 0;
-        // ---- the loader: stage t = B rows c0 + 16 t .. + 15, whole 256-column rows, into slot t % NS
-        const char *gsrc = reinterpret_cast<const char *>(a.B) + ((int64_t)c0 * a.ldb + 4 * lane) * 4;
-        const int64_t row_bytes = a.ldb * 4;
-        const uint32_t ring_b = (uint32_t)(size_t)&ring[0];
-        // the pieces' A operands travel the same way: per piece and stage ONE DMA -- lane (kq, i16) fetches A[i16][16 t + 4 kq .. +3]
-        // (what spmm_block_items loads into registers) -- so the consumers issue no global load at all inside their loop
-        const float *asrc[K::NC];
-        int anst[K::NC];
-#pragma unroll
-        for (int q = 0; q < K::NC; ++q) {
-            const int qq = q < np ? q : 0;                                           // a missing piece: piece 0's operands again (never read)
-            const int bl = (qq < m0 ? 0 : 16) + 2 + 6 * (qq < m0 ? qq : qq - m0);
-            const int qk0 = __builtin_amdgcn_readlane(rec, bl + 1), qlen = __builtin_amdgcn_readlane(rec, bl + 2);
-            const int qp0 = __builtin_amdgcn_readlane(rec, bl + 4), qrl = __builtin_amdgcn_readlane(rec, bl + 5);
-            asrc[q] = a.vals + qp0 + (lane & 15) * qrl + qk0 + 4 * (lane >> 4);
-            anst[q] = qlen / K::SR;
-        }
-        for (int t = 0; t < nst_all; ++t) {
-            int spins = 0;
-            const unsigned long long ws0 = __builtin_amdgcn_s_memtime();
-            for (;;) {                                                               // every consumer is done with stage t - NS
-                const int d0 = hub_flag_load(&flags[4]), d1 = hub_flag_load(&flags[5]), d2 = hub_flag_load(&flags[6]), d3 = hub_flag_load(&flags[7]);
-                const int dm = min(min(d0, d1), min(d2, d3));
-                if (dm >= t - K::NS + 1) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > K::SPIN_LIMIT) { if (lane == 0) atomicOr(a.err, 1u); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-            }
-            w_slot += __builtin_amdgcn_s_memtime() - ws0;
-            asm volatile("" ::: "memory");
-            const uint32_t dst = ring_b + (uint32_t)(t % K::NS) * (K::SLOT_FLOATS * 4);
-            const char *src = gsrc + (int64_t)(K::SR * t) * row_bytes;
-#pragma unroll
-            for (int rr = 0; rr < K::SR / K::NL; ++rr) {
-                const int r = K::NL * rr + lj;
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src + r * row_bytes), "s"(dst + (uint32_t)r * 1024u) : "memory");
-            }
-#pragma unroll
-            for (int qq = 0; qq < K::NC / K::NL; ++qq) {
-                const int q = K::NL * qq + lj;
-                unsigned keep;
-                const float *ap = asrc[q] + K::SR * (t < anst[q] ? t : anst[q] - 1);  // past a shorter piece's end: its last stage again, never read
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(ap), "s"(dst + (uint32_t)(K::SR * 1024 + q * 1024)) : "memory");
-            }
-            if (t >= K::D) {
-                const unsigned long long wv0 = __builtin_amdgcn_s_memtime();
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K::DMA_PER_STAGE * K::D) : "memory");   // stage t - D has landed (vector-memory operations retire in order)
-                w_vm += __builtin_amdgcn_s_memtime() - wv0;
-                hub_flag_store(&flags[lj], t - K::D + 1);
-                if (t == K::D) t_first = __builtin_amdgcn_s_memtime();
-            }
-        }
-        if (nst_all >= 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K::DMA_PER_STAGE) : "memory");
-            hub_flag_store(&flags[lj], nst_all - 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // nothing may land after this wave has gone
-        hub_flag_store(&flags[lj], nst_all);
-        stamp(2, t_first); stamp(3, __builtin_amdgcn_s_memtime()); stamp(4, w_slot); stamp(5, w_vm); stamp(6, (unsigned long long)nst_all); stamp(7, (unsigned long long)np);
-        return;
-    }
-
-    // ---- consumers: wave w takes piece w of the workgroup
-    const int w = wave;
-    if (w >= np) return;                                                              // its done word says INT_MAX already
-    const int base_l = (w < m0 ? 0 : 16) + 2 + 6 * (w < m0 ? w : w - m0);      // the piece's six dwords in `rec` (wave-uniform lane index)
-    const int pg = __builtin_amdgcn_readlane(rec, base_l);
-    const int pk0 = __builtin_amdgcn_readlane(rec, base_l + 1), plen = __builtin_amdgcn_readlane(rec, base_l + 2);
-    const int pfl = __builtin_amdgcn_readlane(rec, base_l + 3), pp0 = __builtin_amdgcn_readlane(rec, base_l + 4);
-    const int prl = __builtin_amdgcn_readlane(rec, base_l + 5);
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int colv = 4 * i16;
-    const int nst = plen / K::SR;
-    (void)pp0; (void)prl; (void)pk0;                                                   // (the loader addresses A; the consumer only needs the tile's rows)
-
-    float4a acc[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = (float4a){0.f, 0.f, 0.f, 0.f};
-    const int r0 = pg << 4;
-    if (pfl & kPieceCarryIn) {
-        float4v T[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float *cp = a.C + (int64_t)(r0 + 4 * kq + q) * a.ldc + colv;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) T[q][x] = *reinterpret_cast<const float4v *>(cp + 64 * x);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * x + e][q] = T[q][x][e];
-    }
-    // The stage loop is unrolled over the NS ring slots (static LDS offsets).  No global load inside it: B rows AND this piece's A
-    // operands are in the slot (the loader's DMAs), so nothing here waits on vmcnt.
-    const float *lbase = &ring[kq * 256 + 4 * i16];
-    auto read_b = [&](float4v (&bx)[4], const float *sb, int s) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) bx[x] = *reinterpret_cast<const float4v *>(sb + s * 1024 + 64 * x);
-    };
-    unsigned long long w_poll = 0, t_s0 = 0;
-    stamp(2, __builtin_amdgcn_s_memtime());
-    for (int t0 = 0; t0 < nst; t0 += K::NS) {
-#pragma unroll
-        for (int u = 0; u < K::NS; ++u) {
-            const int t = t0 + u;
-            if (t < nst) {                                                            // wave-uniform
-                {
-                    const unsigned long long wp0 = __builtin_amdgcn_s_memtime();
-                    int spins = 0;
-                    while (min(hub_flag_load(&flags[0]), hub_flag_load(&flags[1])) < t + 1) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > K::SPIN_LIMIT) { if (lane == 0) atomicOr(a.err, 2u); hub_flag_store(&flags[4 + w], 0x7fffffff); return; }
-                    }
-                    asm volatile("" ::: "memory");
-                    w_poll += __builtin_amdgcn_s_memtime() - wp0;
-                    if (t == 0) t_s0 = __builtin_amdgcn_s_memtime();
-                }
-                const float *sb = lbase + u * K::SLOT_FLOATS;
-                float4v b0[4], b1[4];
-                read_b(b0, sb, 0);
-                // the stage's A operands into MFMA shape: lane kq holds k = 4 s + kq in step s (4 x 4 transpose across the 16-lane rows)
-                float at[4];
-                {
-                        const float4v arw = *reinterpret_cast<const float4v *>(&ring[u * K::SLOT_FLOATS + K::SR * 256 + w * 256 + 4 * lane]);
-                    const unsigned v0 = __float_as_uint(arw[0]), v1 = __float_as_uint(arw[1]), v2 = __float_as_uint(arw[2]), v3 = __float_as_uint(arw[3]);
-                    const auto r02 = __builtin_amdgcn_permlane32_swap(v0, v2, false, false);
-                    const auto r13 = __builtin_amdgcn_permlane32_swap(v1, v3, false, false);
-                    const auto s01 = __builtin_amdgcn_permlane16_swap(r02[0], r13[0], false, false);
-                    const auto s23 = __builtin_amdgcn_permlane16_swap(r02[1], r13[1], false, false);
-                    at[0] = __uint_as_float(s01[0]); at[1] = __uint_as_float(s01[1]); at[2] = __uint_as_float(s23[0]); at[3] = __uint_as_float(s23[1]);
-                }
-                auto mfma16 = [&](float av, const float4v (&bx)[4]) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[4 * x + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[x][e], acc[4 * x + e], 0, 0, 0);
-                };
-                // k-step s + 1's B operands are requested BEFORE k-step s's 16 MFMAs (512 cycles of matrix work cover the LDS round trip)
-                __builtin_amdgcn_sched_barrier(0);
-                read_b(b1, sb, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(at[0], b0);
-                __builtin_amdgcn_sched_barrier(0);
-                read_b(b0, sb, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(at[1], b1);
-                __builtin_amdgcn_sched_barrier(0);
-                read_b(b1, sb, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(at[2], b0);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(at[3], b1);
-                asm volatile("" ::: "memory");
-                hub_flag_store(&flags[4 + w], t + 1);      // behind this stage's reads in the wave's LDS queue
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    hub_flag_store(&flags[4 + w], 0x7fffffff);
-    stamp(3, t_s0); stamp(4, __builtin_amdgcn_s_memtime()); stamp(5, w_poll); stamp(7, (unsigned long long)nst);
-    // epilogue: as spmm_block_items (a tile a later pass continues stays cacheable, a final one is nt)
-    const bool carried = (pfl & kPieceCarryOut) != 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t off0 = (int64_t)(r0 + 4 * kq + q) * a.ldc + colv;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            float4v v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[4 * x + e][q];
-            if (carried) *reinterpret_cast<float4v *>(a.C + off0 + 64 * x) = v;
-            else __builtin_nontemporal_store(v, reinterpret_cast<float4v *>(a.C + off0 + 64 * x));
-        }
-    }
-    if (dw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6, __builtin_amdgcn_s_memtime()); }
-}
-
 // Cuts a qualifying group's column list (the list of its first row) into runs of consecutive columns.
 // One wave per group.  out[gi]: n = number of pieces (1..kMaxPieces); piece r covers positions
 // [k0[r], k0[r] + len[r]) of the list and is the column run c0[r], c0[r]+1, ... when c0[r] >= 0;
