@@ -42,6 +42,7 @@ struct mi_spmm_handle {
                           // back into the caller's stream inside every run call (their longest rows then overlap the rows kernel)
     hipStream_t side[2];  // [0]: hub kernel, [1]: segment (+ reduce) kernels; created by the first preprocess that needs them
     int64_t side_priority; // bit 0: the hub stream is a high-priority stream, bit 1: the segment stream is
+    int64_t ftz;          // "flush_denormals": fp32 subnormals flushed like the reference's nvcc --use_fast_math build (spmm_kernels.hpp apply_ftz)
     int64_t segment_overlap; // 1: the segment kernel may go to side stream 1; 0: it stays on the caller's stream, in front of the rows kernel
     hipEvent_t ev_fork, ev_join[2];
     bool fork_recorded, forked[2];   // state of the current run_rows call
@@ -396,7 +397,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         if (e != hipSuccess) return (int)e;
     }
     lap(1);
-    if (h->block_path && block_path_shape_ok(h->feat) && M >= 16 && h->nnz > 0) {
+    if (h->block_path && !h->ftz && block_path_shape_ok(h->feat) && M >= 16 && h->nnz > 0) {
         const int32_t n_groups = (M + 15) / 16;
         if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
         // a group's shared list may be as long as the longest exact segment (auto hub threshold: at most its largest candidate)
@@ -566,6 +567,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
     else if (k == "hub_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->hub_overlap = v; free_plan(h); }
     else if (k == "segment_overlap") { h->segment_overlap = v ? 1 : 0; free_plan(h); }
+    else if (k == "flush_denormals") { h->ftz = v ? 1 : 0; free_plan(h); }       // (the block path is not used with it: preprocess again)
     else if (k == "side_priority") {
         if (v < 0 || v > 3) return MI_SPMM_EINVAL;
         if (v != h->side_priority) {          // the streams are made by the next preprocess
@@ -617,6 +619,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "hub_overlap") *value = h->hub_overlap;
     else if (k == "side_priority") *value = h->side_priority;
     else if (k == "segment_overlap") *value = h->segment_overlap;
+    else if (k == "flush_denormals") *value = h->ftz;
     else if (k == "n_hub_rows") *value = h->split_long ? 0 : h->n_long;
     else if (k == "rows_per_block") *value = h->rows_per_block;
     else if (k == "xcd_remap") *value = h->xcd_remap;
@@ -747,7 +750,7 @@ static int preprocess_plan(mi_spmm_handle *h)
     {
         const int32_t N = h->feat;
         const bool n_ok = block_path_shape_ok(N);
-        if (h->block_path && n_ok && M >= 16 && h->nnz > 0) {
+        if (h->block_path && !h->ftz && n_ok && M >= 16 && h->nnz > 0) {
             const int32_t n_groups = (M + 15) / 16;
             if (hipMalloc((void **)&h->d_blk_flag, (size_t)n_groups) != hipSuccess) return MI_SPMM_ENOMEM;
             const int grid = (n_groups + 3) / 4;  // one wave per group
@@ -1055,7 +1058,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     // auto: measured neutral-to-positive everywhere except one whole-wave row and a single column
     // tile (N = 256), where interleaving rows over the XCDs is ~3 % faster (profiles/r01_sweep_*)
     const bool remap = h->xcd_remap < 0 ? !(lpr == 64 && col_tiles == 1) : (h->xcd_remap != 0);
-    const int flags = remap ? kFlagXcdRemap : 0;
+    const int flags = (remap ? kFlagXcdRemap : 0) | (h->ftz ? kFlagFtz : 0);
     const int pol = (h->nt_store ? kPolNtStore : 0) | (h->nt_stream ? kPolNtStream : 0);
     int launches = 0;
 
@@ -1076,6 +1079,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ha.N = full.N;
         ha.row_lo = row_begin;
         ha.row_hi = row_end;
+        ha.flags = h->ftz ? kFlagFtz : 0;
         ha.po = po_full;
         // Slice width, when the caller leaves it to us: 32 columns per chain wave -- unless the longest row's chain alone
         // (4.1 ns per nonzero) is more than half of what the whole step's bytes take at 6 TB/s, i.e. that one chain is the
@@ -1085,7 +1089,9 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         int sw = (int)h->hub_slice;
         if (sw <= 0) {
             const double step_s = ((double)h->nnz * (4.0 * full.N + 8.0) + 4.0 * (double)h->num_v * full.N) / 6e12;
-            sw = (full.N <= 16 || (double)h->max_row_nnz * 4.1e-9 > 0.5 * step_s) ? 16 : 32;
+            // (round 4, new chain loop: 16 and 32 are within 1-3 % of each other on chain-bound graphs up to N = 128; at N = 256 the 16 workgroups
+            //  of a row cost more than they save: am-shaped 1.164 -> 1.119 ms with 32; 64 loses everywhere it is the chain that counts)
+            sw = (full.N <= 16 || (full.N <= 128 && (double)h->max_row_nnz * 3.3e-9 > 0.5 * step_s)) ? 16 : 32;
         }
         const bool wide_hub = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
                                 ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));

@@ -54,7 +54,17 @@ struct RowsArgs {
     PeerOut po;
 };
 
-enum : int32_t { kFlagXcdRemap = 4, kFlagBlockFallback = 8 };   // fallback: the block kernels cannot run on this call (alignment): the rows kernel takes the block groups' rows, whatever their length
+enum : int32_t { kFlagXcdRemap = 4, kFlagBlockFallback = 8, kFlagFtz = 16 };   // fallback: the block kernels cannot run on this call (alignment): the rows kernel takes the block groups' rows, whatever their length
+
+// "flush_denormals" = 1: the arithmetic of the reference's actual BUILD.  nvcc --use_fast_math (W/CMakeLists.txt:46) implies -ftz=true: every
+// multiply-add of spmm_kernel_ref is fma.rn.ftz.f32 -- subnormal inputs count as sign-preserving zeros, a subnormal result is flushed to a
+// sign-preserving zero.  gfx950 has the same switch per wave: MODE.FP_DENORM bits 5:4 (fp32) = 0 flushes sources and results of v_fma_f32 /
+// v_fmac_f32 / v_pk_fma_f32 alike (the packed form was checked against the reference kernel's own flush-to-zero build: same bits).  Set at kernel entry, ahead of any arithmetic (the wave's MODE starts from the kernel descriptor: IEEE, which is what
+// the default -- and the oracle's canonical form -- keep).  The f32 MFMA does not take part: with the option on the block path is not used.
+__device__ __forceinline__ void apply_ftz(int flags)
+{
+    if (flags & kFlagFtz) __builtin_amdgcn_s_setreg(1 | (4 << 6) | ((2 - 1) << 11), 0);      // hwreg(HW_REG_MODE, offset 4, size 2) <- 0
+}
 
 // Blocks b and b+8 land on the same XCD (round-robin dispatch; speed only,
 // never correctness -- cdna_hip_programming.md T1).  Give each XCD one
@@ -160,6 +170,10 @@ template <int PV> struct Pairs {
     int ci[PV];
     int av[PV];  // float bits
 };
+// An unfetched pair is (column 0, a = -0.0f): where a batch is padded the slot's B operand is +0, and fma(+0, -0, acc) = (-0) + acc is the
+// identity for EVERY acc -- -0 included.  With a = +0 the padding turned an accumulator of -0 (a chain of negative products that underflow)
+// into +0: found in round 4 by the flush-to-zero test, where such accumulators are common; it is reachable in IEEE arithmetic as well.
+constexpr int kPadA = (int)0x80000000u;
 
 template <int PV, bool NT>
 __device__ __forceinline__ Pairs<PV> fetch_pairs(const int32_t *__restrict__ col_idx,
@@ -168,7 +182,7 @@ __device__ __forceinline__ Pairs<PV> fetch_pairs(const int32_t *__restrict__ col
     typedef int ivec __attribute__((ext_vector_type(PV), aligned(4)));
     Pairs<PV> p;
 #pragma unroll
-    for (int i = 0; i < PV; ++i) { p.ci[i] = 0; p.av[i] = 0; }
+    for (int i = 0; i < PV; ++i) { p.ci[i] = 0; p.av[i] = kPadA; }
     if (PV > 1 && kk + PV <= kend) {
         ivec c, v;
         if (NT) {
@@ -231,7 +245,7 @@ item_chain(const Pairs<PV> &cur, int cnt, typename Vec<V>::T acc, const float *_
             b[u] = Vec<V>::zero();
             if (jb + u < cnt) b[u] = Vec<V>::load(b_row_ptr<WIDE>(B, ldb, ldb_bytes, col_bytes, col, c));
         }
-        // slots past cnt carry a = +0, b = +0 (unfetched pairs are zero): exact no-ops
+        // slots past cnt carry a = -0, b = +0 (unfetched pairs: kPadA): exact no-ops for every accumulator, -0 included
 #pragma unroll
         for (int u = 0; u < UNROLL - 1; ++u) acc = Vec<V>::fma(b[u], av[u], acc);
     }
@@ -253,7 +267,7 @@ segment_chain_v2(const int32_t *__restrict__ col_idx, const float *__restrict__ 
     for (int k0 = beg; k0 < end; k0 += CH) {
         Pairs<PV> nxt;
 #pragma unroll
-        for (int i = 0; i < PV; ++i) { nxt.ci[i] = 0; nxt.av[i] = 0; }
+        for (int i = 0; i < PV; ++i) { nxt.ci[i] = 0; nxt.av[i] = kPadA; }
         if (k0 + CH < end) nxt = fetch_pairs<PV, NT>(col_idx, vals, k0 + CH + lig * PV, end);
         acc = item_chain<V, LPR, PV, UNROLL, WIDE>(cur, min(CH, end - k0), acc, B, ldb, ldb_bytes, col_bytes, col);
         cur = nxt;
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
     constexpr bool NTS = (POL & kPolNtStream) != 0;
     static_assert(UNROLL % PV == 0, "a batch must cover whole fetch lanes");
     typedef typename Vec<V>::T T;
+    apply_ftz(a.flags);
     const int tid = threadIdx.x;
     const int g = tid / LPR;
     const int lig = tid % LPR;
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
         }
         Pairs<PV> nxt;
 #pragma unroll
-        for (int i = 0; i < PV; ++i) { nxt.ci[i] = 0; nxt.av[i] = 0; }
+        for (int i = 0; i < PV; ++i) { nxt.ci[i] = 0; nxt.av[i] = kPadA; }
         if (has_next) nxt = fetch_pairs<PV, NTS>(a.col_idx, a.vals, nk0 + lig * PV, nlive ? nend : nk0);
 
         // ---- this item: up to CH nonzeros of row gbase + ri, in stored order
@@ -361,6 +376,7 @@ template <int V, int LPR, int UNROLL, bool WIDE>
 __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
 {
     constexpr int GPB = kBlockThreads / LPR;
+    apply_ftz(a.flags);
     const int tid = threadIdx.x;
     const int g = tid / LPR;
     const int lig = tid % LPR;
@@ -401,6 +417,7 @@ struct ReduceArgs {
 template <int V>
 __global__ __launch_bounds__(kBlockThreads) void spmm_reduce_chunks(ReduceArgs a)
 {
+    apply_ftz(a.flags);
     const int vec_per_row = (a.N + V - 1) / V;
     const int64_t t = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
     const int64_t lr = t / vec_per_row;
@@ -461,6 +478,7 @@ struct HubArgs {
     int32_t N;
     int32_t slices;          // ceil(N / SW); gridDim.x = slices * n_hubs
     int32_t row_lo, row_hi;  // rows outside [row_lo, row_hi) are skipped (row panels)
+    int32_t flags;           // kFlagFtz
     PeerOut po;
 };
 
@@ -496,6 +514,7 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
     constexpr int L = K::L, U = K::U, LPS = K::LPS, NG = K::NG, NBK = K::NBK, CS = K::CS, NB = K::NB;
     __shared__ __attribute__((aligned(16))) float ring[K::LDS_BYTES / 4];
     __shared__ int flags[16];                                   // [0] pub: stages 0 .. pub-1 are in the ring (INT_MAX once the row's last one is); [L] done: stages consumed
+    apply_ftz(a.flags);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;
@@ -736,7 +755,7 @@ template <> struct BVec<2> { typedef float2v T; };
 // Pieces of an item are ordered longest first and every shared piece's length is a multiple of
 // kShareLenUnit (a whole number of batch pairs), so the k loop is two plain loops: the batches in which both
 // pieces run, then the longest piece's remainder alone.  Only the longest piece can end inside a batch (its
-// missing rows are zero B operands times zero A operands: exact no-ops) -- a shorter piece never meets the
+// missing rows are +0 B operands times -0 A operands: exact no-ops for every accumulator) -- a shorter piece never meets the
 // longer one's extra B rows, so an inf or NaN there cannot reach it.
 template <int XC, int V, int G, bool WIDE, bool RUN>
 __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a)
@@ -933,7 +952,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
         __builtin_amdgcn_sched_barrier(0);
 
         // the MFMAs of one batch: every B operand feeds NA pieces.  List items: operands of k-rows past the end of the
-        // list become zeros here (0 * 0 terms are exact no-ops); run items never compute a batch past a piece's end.
+        // list become (+0) x (-0) terms here (exact no-ops, an accumulator of -0 included); run items never compute a batch past a piece's end.
         auto compute = [&](auto na_tag, const BV (&R)[LOADS], const float (&af)[G][KS], int kb) {
             constexpr int NA = decltype(na_tag)::value;
 #pragma unroll
@@ -941,7 +960,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void spmm_block_items(BlockArgs a
                 const int k = kb + 4 * s + kq;
                 float av[NA];
 #pragma unroll
-                for (int j = 0; j < NA; ++j) av[j] = (RUN || k < slen[j]) ? af[j][s] : 0.f;
+                for (int j = 0; j < NA; ++j) av[j] = (RUN || k < slen[j]) ? af[j][s] : -0.f;      // (-0) x (+0) + acc = acc for every acc, -0 included
 #pragma unroll
                 for (int x = 0; x < XC; ++x)
 #pragma unroll

@@ -29,7 +29,9 @@
  *     EVERY row is that chain, bit for bit, whatever its length (short rows,
  *     single segments, hub rows through the hub kernel, block groups through
  *     the f32 MFMA).  Only the opt-in "split_long_rows" = 1 sums rows longer
- *     than the threshold piece by piece (tolerance: DESIGN.md).
+ *     than the threshold piece by piece (tolerance: DESIGN.md).  The reference's BUILD
+ *     additionally flushes fp32 subnormals (nvcc --use_fast_math => -ftz=true): opt-in
+ *     "flush_denormals" = 1 reproduces that too, bit for bit.
  *
  * Errors: the reference aborts (include/util.h:63-84).  The C ABI never
  * aborts: every function returns 0 on success or a negative MI_SPMM_E* /
@@ -141,6 +143,13 @@ const char *mi_spmm_strerror(int code);
  *                         one after the other and the step is slower than with no side stream at all; with one side stream that
  *                         cannot happen, and it measured equal or faster on every shape (profiles/r04_side_streams.txt)
  *   "side_priority"       bit 0 / bit 1: the hub / segment side stream is a high-priority stream (default 3)
+ *   "flush_denormals"     0 (default): IEEE fp32 arithmetic, subnormals kept -- the canonical definition (spmm_ref.cu:10-14 with fma contraction).
+ *                         1: the arithmetic of the reference's actual BUILD: nvcc --use_fast_math (CMakeLists.txt:46) implies -ftz=true, so
+ *                         its multiply-adds are fma.rn.ftz.f32 -- subnormal inputs count as sign-preserving zeros, subnormal results are
+ *                         flushed to sign-preserving zeros.  Implemented with the wave's own mode register (MODE.FP_DENORM, set at kernel
+ *                         entry); bit-identical to spmm_kernel_ref compiled with the matching switch (hipcc -fgpu-flush-denormals-to-zero)
+ *                         on data full of subnormals.  The f32 MFMA block path is not used with it.  On data that holds no subnormals and
+ *                         produces none (the reference's N(0, 0.1) inputs) the two settings give the same bits.
  *   "use_graph"           0 (default) / 1: the step's launch set (2-4 kernels plus the side streams' fork and join) is captured once
  *                         into a HIP graph on a handle-owned stream and run() replays it with ONE hipGraphLaunch on the caller's
  *                         stream -- for steps of tens of microseconds (small graphs) the launches are the step.  preprocess captures

@@ -17,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "liboracle.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libspmm_ref_gfx950.so")
+REF_LIB_FTZ = os.path.join(_HERE, "_ref", "libspmm_ref_gfx950_ftz.so")     # the same reference kernels, hipcc -fgpu-flush-denormals-to-zero (nvcc -ftz=true)
 
 _lib = None
 _ref = None
@@ -97,6 +98,8 @@ def lib():
         L.oracle_spmm_nofma.restype = None
         L.oracle_spmm_omp.argtypes = [P, P, P, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.oracle_spmm_omp.restype = None
+        L.oracle_spmm_ftz.argtypes = [P, P, P, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32]
+        L.oracle_spmm_ftz.restype = None
         L.oracle_spmm_f64.argtypes = [P, P, P, P, P, P, C.c_int32, C.c_int32]
         L.oracle_spmm_f64.restype = None
         L.oracle_valid_float.argtypes = [P, P, C.c_int64]
@@ -156,6 +159,17 @@ def spmm_omp(ptr, idx, val, vin, out=None, row_begin=0, row_end=-1, feat=None, l
     if out is None:
         out = np.empty((num_v, feat), dtype=np.float32)
     lib().oracle_spmm_omp(_p(ptr), _p(idx), _p(val), _p(vin), ldb, _p(out), out.shape[1], num_v, feat, row_begin, row_end)
+    return out
+
+
+def spmm_ftz(ptr, idx, val, vin):
+    """The reference's BUILD semantics (nvcc --use_fast_math => fma.rn.ftz.f32): subnormal inputs and results flushed to
+    sign-preserving zeros around every fused multiply-add; stored order, +0 start."""
+    ptr, idx, val = _csr(ptr, idx, val)
+    vin = np.ascontiguousarray(vin, dtype=np.float32)
+    num_v = ptr.size - 1
+    out = np.empty((num_v, vin.shape[1]), dtype=np.float32)
+    lib().oracle_spmm_ftz(_p(ptr), _p(idx), _p(val), _p(vin), vin.shape[1], _p(out), vin.shape[1], num_v, vin.shape[1])
     return out
 
 
@@ -265,6 +279,29 @@ def ref_lib():
         L.ref_valid_int.restype = C.c_int
         _ref = L
     return _ref
+
+
+_ref_ftz = None
+
+
+def ref_ftz_available():
+    return os.path.exists(REF_LIB_FTZ)
+
+
+def ref_kernel_run_ftz(d_ptr, d_idx, d_val, d_vin, d_vout, num_v, feat, stream=0):
+    """spmm_kernel_ref itself built the way the reference builds it with respect to subnormals: hipcc -fgpu-flush-denormals-to-zero
+    (= nvcc -ftz=true, implied by --use_fast_math, CMakeLists.txt:46)."""
+    global _ref_ftz
+    if _ref_ftz is None:
+        L = C.CDLL(REF_LIB_FTZ)
+        P = C.c_void_p
+        L.ref_spmm_ref_run.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
+        L.ref_spmm_ref_run.restype = C.c_int
+        _ref_ftz = L
+    rc = _ref_ftz.ref_spmm_ref_run(d_ptr.data_ptr(), d_idx.data_ptr(), d_val.data_ptr(), d_vin.data_ptr(),
+                                   d_vout.data_ptr(), int(num_v), int(feat), stream)
+    if rc:
+        raise RuntimeError(f"ref_spmm_ref_run (ftz build) -> hip error {rc}")
 
 
 def ref_kernel_run(d_ptr, d_idx, d_val, d_vin, d_vout, num_v, feat, stream=0):

@@ -89,6 +89,36 @@ void oracle_spmm_omp(const int32_t *ptr, const int32_t *idx, const float *val,
     }
 }
 
+/* The reference's actual BUILD: nvcc -O3 --use_fast_math (CMakeLists.txt:46) implies -ftz=true, so every `result += vin[..] * val[i]`
+ * of spmm_ref.cu:13 is fma.rn.ftz.f32 (PTX ISA, "fma": with .ftz, subnormal inputs and results are flushed to sign-preserving zero).
+ * Restated: flush the three inputs, one correctly rounded fused multiply-add, flush the result.  On inputs that hold no fp32
+ * subnormals and produce none (the reference's own N(0, 0.1) data) this is oracle_spmm_omp bit for bit; tests assert that too.
+ * The product's counterpart is the opt-in "flush_denormals" = 1 (include/mi_spmm.h). */
+static inline float oracle_ftz(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0) u &= 0x80000000u;      /* zero or subnormal -> zero of the same sign */
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+void oracle_spmm_ftz(const int32_t *ptr, const int32_t *idx, const float *val,
+                     const float *vin, int64_t ldb, float *vout, int64_t ldc,
+                     int32_t num_v, int32_t feat)
+{
+#pragma omp parallel for schedule(dynamic, 64) if (num_v >= 512)
+    for (int32_t r = 0; r < num_v; ++r) {
+        const int32_t begin = ptr[r], end = ptr[r + 1];
+        for (int32_t j = 0; j < feat; ++j) {
+            float result = 0.0f;
+            for (int32_t i = begin; i < end; ++i)
+                result = oracle_ftz(fmaf(oracle_ftz(vin[(int64_t)idx[i] * ldb + j]), oracle_ftz(val[i]), oracle_ftz(result)));
+            vout[(int64_t)r * ldc + j] = result;
+        }
+    }
+}
+
 /* Documentation variant: separate multiply and add (what a build WITHOUT fmad
  * would give).  Not the oracle; used by one test that records how far the
  * two contraction modes sit apart. */

@@ -19,7 +19,7 @@ cases = {"c2": lambda: synth.csr_powerlaw(1 << 20, 32.0, 4096), "rmat": lambda: 
          "am": shaped("am", 881_680, 5_668_682, 154_828), "arxiv": shaped("arxiv", 169_343, 1_166_243, 13_155),
          "youtube": shaped("youtube", 1_138_499, 5_980_886, 28_754), "ddi": shaped("ddi", 4_267, 2_135_822, 2_234),
          "reddit": shaped("reddit.dgl", 232_965, 114_615_892, 21_657), "protein": shaped("protein", 132_534, 79_122_504, 7_750)}
-variants = [("hub", {}), ("hubser", {"hub_overlap": 0}), ("hub16", {"hub_slice": 16}), ("hub64", {"hub_slice": 64}), ("split", {"split_long_rows": 1}), ("nohub", {"long_row_threshold": 1 << 30})]
+variants = [("hub", {}), ("hubser", {"hub_overlap": 0}), ("hub16", {"hub_slice": 16}), ("hub32", {"hub_slice": 32}), ("hub64", {"hub_slice": 64}), ("split", {"split_long_rows": 1}), ("nohub", {"long_row_threshold": 1 << 30})]
 for thr in (256, 512, 1024, 2048, 4096, 8192):
     variants.append((f"hubt{thr}", {"long_row_threshold": thr}))
 if os.environ.get("HUB_VARIANTS"):

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from hpc_amd import synth
+from conftest import bits
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -152,3 +153,32 @@ def test_fill_normal_restatement_statistics(oracle):
     b = oracle.fill_normal(4000, 5, 7)
     assert np.array_equal(a, b[:1001])                                # element i depends on (seed, subseq, i) only
     assert not np.array_equal(oracle.fill_normal(64, 5, 8), b[:64])
+
+
+def test_flush_to_zero_restatement_of_the_reference_build(oracle):
+    """The reference is BUILT with nvcc --use_fast_math (W/CMakeLists.txt:46) => -ftz=true => fma.rn.ftz.f32: subnormal inputs and results
+    are flushed to sign-preserving zeros.  oracle.spmm_ftz restates that; on data without subnormals it is the canonical oracle bit for bit."""
+    f32 = np.float32
+    sub = np.frombuffer(np.uint32(0x00012345).tobytes(), f32)[0]          # a subnormal (~1.07e-40)
+    assert 0 < sub < np.finfo(f32).tiny
+    ptr = np.array([0, 1, 2, 4, 6, 7], np.int32)
+    idx = np.array([0, 1, 2, 2, 0, 1, 3], np.int32)
+    val = np.array([sub, f32(1e-20), f32(1.0), f32(1.0), f32(-1e-20), f32(3.0), -sub], f32)
+    B = np.array([[1e10], [1e-20], [0.5], [4.0]], f32)
+    plain = oracle.spmm_omp(ptr, idx, val, B)
+    ftz = oracle.spmm_ftz(ptr, idx, val, B)
+    # row 0: subnormal a times 1e10 -- a normal number in IEEE arithmetic, nothing once the input is flushed
+    assert plain[0, 0] > 0 and ftz[0, 0] == 0.0 and not np.signbit(ftz[0, 0])
+    # row 1: 1e-20 * 1e-20 = 1e-40: a subnormal RESULT, flushed
+    assert 0 < plain[1, 0] < np.finfo(f32).tiny and ftz[1, 0] == 0.0
+    # row 2: normal terms are untouched
+    assert ftz[2, 0] == plain[2, 0] == f32(1.0)
+    # row 3: -1e-20 * 1e10 + 3 * 1e-20: normal, untouched;  row 4: negative subnormal input: -0 * 4 = -0, added to +0 = +0
+    assert ftz[3, 0] == plain[3, 0] and ftz[4, 0] == 0.0 and not np.signbit(ftz[4, 0])
+    # a subnormal result keeps its sign as a zero: (-1e-20) * (1e-20) from a -0 accumulator ... start is +0, so the sum is +0; check the product alone
+    pn = oracle.spmm_ftz(np.array([0, 1], np.int32), np.array([0], np.int32), np.array([-1e-20], f32), np.array([[1e-20], ], f32))
+    assert pn[0, 0] == 0.0       # fma(-1e-20, 1e-20, +0) = -1e-40 -> flushed to -0; -0 == 0, and the stored bits are the sign-preserving zero:
+    assert bits(pn)[0, 0] == 0x80000000
+    # the reference's own kind of data (N(0, 0.1), BASELINE configs[0]) holds no subnormals and makes none: both forms agree on every bit
+    p0, i0, v0, B0, _ = synth.config("C0")
+    assert np.array_equal(bits(oracle.spmm_ftz(p0, i0, v0, B0)), bits(oracle.spmm_omp(p0, i0, v0, B0)))

@@ -1031,6 +1031,102 @@ def test_use_graph_replays_the_captured_launch_set(device, oracle, overlap):
     assert np.array_equal(bits(C1), bits(oracle.spmm_omp(ptr[:101], idx[:ptr[100]], vals[:ptr[100]], B))) and op1.get_option("graph_replays") == 1
 
 
+def test_negative_zero_accumulators_survive_padded_batches(device, oracle):
+    """A chain of negative products that all underflow leaves the accumulator at -0 (fma(-1e-30, 1e-30, +0) is -1e-60 exactly and rounds to -0;
+    -0 + -0 stays -0), and the reference kernel stores that -0.  The kernels pad their last batch of a row: the padding must be an identity for
+    -0 too -- (+0) x (-0) + acc, not (+0) x (+0) + acc, which turns -0 into +0 (round 4; found by the flush-to-zero test).  Every row length around
+    the batch sizes (8 gathers, 32- and 64-pair fetches), every kernel class, N = 32 / 128 / 256 (one, two lane groups per wave, whole-wave rows),
+    block-dense groups through the list kernel's masked tail."""
+    import torch
+
+    lens = list(range(0, 20)) + [31, 32, 33, 63, 64, 65, 100, 257, 600, 2000, 7, 9] + [11] * 16 + [5] * 16     # rows 32-47 and 48-63: two 16-row groups
+    M = len(lens)
+    assert M == 64
+    K = 1000
+    g = np.random.Generator(np.random.Philox(key=[31, 7]))
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = g.integers(0, K, size=int(ptr[-1])).astype(np.int32)
+    for r0, L in ((32, 11), (48, 5)):                 # one shared column list per group (lengths 11 and 5: the list kernel's masked last batch)
+        cols = g.integers(0, K, size=L).astype(np.int32)
+        for r in range(r0, r0 + 16):
+            idx[ptr[r]:ptr[r + 1]] = cols
+    vals = (-np.abs(g.normal(size=idx.size)) * 1e-30).astype(np.float32)          # every product: negative, ~1e-60: underflows to -0
+    for N in (32, 128, 256):
+        B = (np.abs(g.normal(size=(K, N))) * 1e-30 + 1e-32).astype(np.float32)
+        exp = oracle.spmm_omp(ptr, idx, vals, B)
+        nz = np.array(lens) > 0
+        assert (bits(exp)[nz] == 0x80000000).all() and (bits(exp)[~nz] == 0).all()      # -0 in every non-empty row, +0 in the empty ones
+        if oracle.ref_available():
+            d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+            R = torch.full((M, N), float("nan"), device=device)
+            oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, R, M, N)
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(R.cpu().numpy()), bits(exp))
+        for opts in ({}, {"long_row_threshold": 512, "medium_row_threshold": 16}, {"long_row_threshold": 64, "medium_row_threshold": 8, "hub_slice": 16},
+                     {"block_min_len": 4}, {"block_min_len": 4, "long_row_threshold": 256}, {"long_row_threshold": 256, "split_long_rows": 1}):
+            C, op = run_spmm(device, ptr, idx, vals, B, options=opts, num_cols=K)
+            if "block_min_len" in opts:
+                assert op.get_option("n_block_groups") == 2
+            bad = np.nonzero((bits(C) != bits(exp)).any(axis=1))[0]
+            assert bad.size == 0, (N, opts, [(int(r), lens[r]) for r in bad[:10]])
+
+
+def test_flush_denormals_matches_the_reference_build(device, oracle):
+    """ "flush_denormals" = 1 is the arithmetic of the reference's actual BUILD: nvcc --use_fast_math (W/CMakeLists.txt:46) implies -ftz=true, so
+    spmm_kernel_ref's multiply-adds are fma.rn.ftz.f32.  Data full of fp32 subnormals (values, B, and products that land in the subnormal
+    range), through every kernel class (short rows, exact segments, hub rows at every slice width, rows of block-dense groups): the product
+    equals BOTH the reference kernel compiled with the matching switch (hipcc -fgpu-flush-denormals-to-zero, oracle/_ref) AND the CPU
+    restatement of fma.ftz, bit for bit -- and differs from the IEEE result, which the default option still reproduces."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    if not (oracle.ref_available() and oracle.ref_ftz_available()):
+        pytest.fail("oracle/_ref missing: run __graft_entry__.build() in the CPU container first")
+    g = np.random.Generator(np.random.Philox(key=[909, 1]))
+    K = 4000
+    lens = [0, 3, 17, 40, 70, 200, 700, 3000] * 6 + [5] * 32         # 80 rows; the last 32 form two 16-row groups below
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = g.integers(0, K, size=int(ptr[-1])).astype(np.int32)
+    shared = g.integers(0, K, size=5).astype(np.int32)               # two block-dense groups: 16 rows x one column list of 5 (block_min_len lowered)
+    for r in range(48, 80):
+        idx[ptr[r]:ptr[r + 1]] = shared
+    # every row of A has its own scale (1 ... 1e-36) and every row of B one of 1, 1e-4, 1e-8 (a tenth of them 1e-40: subnormal inputs): a row's products sit together somewhere between
+    # 1 and 1e-44, so whole output rows live in or next to the subnormal range instead of being dominated by their largest term
+    row_exp = g.choice([0.0, -20.0, -30.0, -36.0], size=len(lens))
+    vals = (g.normal(size=idx.size) * np.power(10.0, np.repeat(row_exp, lens))).astype(np.float32)
+    for N in (32, 128, 260):
+        B = (g.normal(size=(K, N)) * np.power(10.0, g.choice([0.0, -4.0, -8.0, -40.0], size=(K, 1), p=[0.3, 0.3, 0.3, 0.1]))).astype(np.float32)
+        assert (np.abs(vals[vals != 0]) < np.finfo(np.float32).tiny).any() and (np.abs(B[B != 0]) < np.finfo(np.float32).tiny).any()
+        ieee = oracle.spmm_omp(ptr, idx, vals, B)
+        ftz = oracle.spmm_ftz(ptr, idx, vals, B)
+        n_differ = int((bits(ieee) != bits(ftz)).sum())
+        assert n_differ > ieee.size // 8, "the data must make the two arithmetics differ, or the test shows nothing"
+        d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+        M = len(lens)
+        R = torch.full((M, N), float("nan"), device=device)
+        oracle.ref_kernel_run_ftz(d_ptr, d_idx, d_val, d_B, R, M, N)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(R.cpu().numpy()), bits(ftz)), "the CPU restatement of fma.ftz must be what the reference kernel's ftz build computes"
+        oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, R, M, N)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(R.cpu().numpy()), bits(ieee))
+        for opts in ({}, {"hub_slice": 16}, {"hub_slice": 64}, {"long_row_threshold": 1 << 30}, {"hub_overlap": 2, "segment_overlap": 1}):
+            o = {"long_row_threshold": 512, "medium_row_threshold": 32, "block_min_len": 4, "flush_denormals": 1}
+            o.update(opts)
+            C, op = run_spmm(device, ptr, idx, vals, B, options=o, num_cols=K)
+            assert op.get_option("flush_denormals") == 1 and op.get_option("n_block_groups") == 0      # the f32 MFMA path is not used with it
+            assert np.array_equal(bits(C), bits(ftz)), (N, opts, int((bits(C) != bits(ftz)).sum()))
+        # the default keeps IEEE subnormals, block path included
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512, "medium_row_threshold": 32, "block_min_len": 4}, num_cols=K)
+        assert op.get_option("n_block_groups") == (2 if N % 32 == 0 else 0)
+        assert np.array_equal(bits(C), bits(ieee))
+        # split mode under ftz: pieces and their left-to-right sum flush as well; checked against the oracle's fma.ftz pieces added with flushing
+        # only where nothing subnormal arises is not the point here: just that it runs and keeps the documented tolerance against the ftz chain
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": 512, "split_long_rows": 1, "flush_denormals": 1}, num_cols=K)
+        _, sabs = oracle.spmm_f64(ptr, idx, vals, B)
+        assert (np.abs(C.astype(np.float64) - ftz) <= TOL_SPLIT * sabs + 1e-33).all()      # (flushed terms: up to ~1.2e-38 each)
+
+
 def test_rmat_and_banded_structures(device, oracle):
     """Hub-dominated (R-MAT) and locality-rich (banded) graphs: every row bit-exact by default (hubs through the hub
     kernel); with "split_long_rows" the hubs follow the documented piece order."""
