@@ -33,6 +33,7 @@ SIGNATURES = {
     "mi_spmm_fill_normal": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _P]),
     "mi_spmm_fill_philox_u32": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "mi_spmm_unpack_gathered": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _P]),
+    "mi_spmm_stream_create_concurrent": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
     "mi_spmm_abi_version": (C.c_int, []),
     "mi_spmm_build_info": (C.c_char_p, []),
 }

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,7 @@ struct mi_spmm_handle {
     int64_t hub_overlap;  // 1 (default): the hub kernel and the segment kernel run on handle-owned side streams, forked from and joined
                           // back into the caller's stream inside every run call (their longest rows then overlap the rows kernel)
     hipStream_t side[2];  // [0]: hub kernel, [1]: segment (+ reduce) kernels; created by the first preprocess that needs them
+    int32_t side_overlaps[2]; // concurrent_stream's verdict on each side stream (1: its kernels run beside the null stream's)
     int64_t side_priority; // bit 0: the hub stream is a high-priority stream, bit 1: the segment stream is
     int64_t ftz;          // "flush_denormals": fp32 subnormals flushed like the reference's nvcc --use_fast_math build (spmm_kernels.hpp apply_ftz)
     int64_t segment_overlap; // 1: the segment kernel may go to side stream 1; 0: it stays on the caller's stream, in front of the rows kernel
@@ -332,6 +334,60 @@ static bool range_has_hub(const mi_spmm_handle *h, int32_t row_begin, int32_t ro
 
 // The hub kernel's longest row is the step's longest dependent chain; on a side stream it runs beside the rows kernel
 // instead of in front of it.  The stream and its two events belong to the handle (created once, here, never in run()).
+// A side stream is only worth its fork if its kernels RUN BESIDE the caller's.  The runtime hands a process's streams a few hardware
+// queues per priority, in creation order, and the queues sit on a handful of command-processor pipes: a high-priority queue that shares its
+// pipe with the caller's queue is served FIRST, not alongside -- the hub kernel then runs alone and the rows kernel after it (youtube-shaped
+// N = 32: 0.32 ms instead of 0.17), and which handle gets such a queue is a matter of how many streams the process has made before
+// (every other handle in a loop that makes one stream per handle: profiles/r04_side_streams.txt).  So a candidate stream is TESTED: a 40 us
+// spin kernel on it and one on the null stream (the reference's stream, util.h:133-136, and torch's default) -- beside each other they take
+// ~40 us, one after the other ~80 -- and a stream that fails is kept aside (so that the next one made gets another queue) until one passes
+// or four have been tried.  preprocess only (it synchronises anyway); ~0.2 ms per candidate, once per handle.
+static int concurrent_stream(hipStream_t *out, int priority, int *overlaps_out)
+{
+    constexpr int kTries = 4;
+    hipStream_t cand[kTries] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t e0 = nullptr, e1 = nullptr, ef = nullptr, ej = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+    int chosen = -1, made = 0;
+    const unsigned long long ticks = 4000;      // 40 us of the 100 MHz counter
+    for (int t = 0; t < kTries && e == hipSuccess && chosen < 0; ++t) {
+        e = hipStreamCreateWithPriority(&cand[t], hipStreamNonBlocking, priority);
+        if (e != hipSuccess) break;
+        ++made;
+        float best = 1e30f;
+        for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {      // the first pair also pays the queue's first use
+            e = hipEventRecord(e0, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(ef, nullptr);
+            if (e == hipSuccess) e = hipStreamWaitEvent(cand[t], ef, 0);
+            if (e == hipSuccess) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand[t], ticks, (unsigned int *)nullptr); e = hipGetLastError(); }
+            if (e == hipSuccess) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, nullptr, ticks, (unsigned int *)nullptr); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipEventRecord(ej, cand[t]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(nullptr, ej, 0);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        if (std::getenv("MI_SPMM_DEBUG")) std::fprintf(stderr, "[mi_spmm] side stream candidate %d: spin pair %.1f us\n", t, best * 1e3f);
+        if (e == hipSuccess && best < 0.078f) chosen = t;          // measured: 65-70 us beside each other (40 + launch and event overhead), 88-120 one after the other
+    }
+    const int keep = chosen >= 0 ? chosen : 0;
+    for (int t = 0; t < made; ++t)
+        if (t != keep && cand[t]) (void)hipStreamDestroy(cand[t]);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (ef) (void)hipEventDestroy(ef);
+    if (ej) (void)hipEventDestroy(ej);
+    if (e != hipSuccess) { if (made > 0 && cand[keep]) (void)hipStreamDestroy(cand[keep]); return (int)e; }
+    *out = cand[keep];
+    *overlaps_out = chosen >= 0 ? 1 : 0;
+    return MI_SPMM_OK;
+}
+
 static int ensure_side_streams(mi_spmm_handle *h)
 {
     // A fork + join costs ~20 us of launch latency per run call (ddi-shaped N = 32: 0.047 -> 0.069 ms): worth it once the
@@ -342,14 +398,18 @@ static int ensure_side_streams(mi_spmm_handle *h)
     const bool exact_hubs = h->n_long > 0 && !h->split_long;
     h->overlap_on[0] = exact_hubs && (h->hub_overlap == 2 || (h->hub_overlap == 1 && (long_step || h->max_row_nnz >= 7000)));
     h->overlap_on[1] = h->segment_overlap && h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
-    if (!(h->overlap_on[0] || h->overlap_on[1]) || h->side[0]) return MI_SPMM_OK;
+    if (!(h->overlap_on[0] || h->overlap_on[1])) return MI_SPMM_OK;
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (!h->ev_fork) HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, ((h->side_priority >> i) & 1) ? hi : 0));
+        if (!h->overlap_on[i] || h->side[i]) continue;          // made once per handle, and only the ones this plan uses
+        int ov = 0;
+        const int rc = concurrent_stream(&h->side[i], ((h->side_priority >> i) & 1) ? hi : 0, &ov);
+        if (rc != MI_SPMM_OK) return rc;
+        h->side_overlaps[i] = ov;
         HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     return MI_SPMM_OK;
 }
 
@@ -618,6 +678,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "hub_slice") *value = h->hub_slice;
     else if (k == "hub_overlap") *value = h->hub_overlap;
     else if (k == "side_priority") *value = h->side_priority;
+    else if (k == "side_stream_overlaps") *value = h->side[0] ? h->side_overlaps[0] : -1;
     else if (k == "segment_overlap") *value = h->segment_overlap;
     else if (k == "flush_denormals") *value = h->ftz;
     else if (k == "n_hub_rows") *value = h->split_long ? 0 : h->n_long;
@@ -1433,6 +1494,21 @@ int mi_spmm_count_bitdiff(const float *d_a, const float *d_b, int64_t n, int64_t
                           float *maxabs_out, void *stream)
 {
     return compare_common(d_a, d_b, n, 2, ndiff_out, maxabs_out, stream);
+}
+
+int mi_spmm_stream_create_concurrent(void **stream_out, int high_priority, int *overlaps_out)
+{
+    if (!stream_out) return MI_SPMM_EINVAL;
+    *stream_out = nullptr;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
+    hipStream_t s = nullptr;
+    int ov = 0;
+    const int rc = concurrent_stream(&s, high_priority ? hi : 0, &ov);
+    if (rc != MI_SPMM_OK) return rc;
+    *stream_out = (void *)s;
+    if (overlaps_out) *overlaps_out = ov;
+    return MI_SPMM_OK;
 }
 
 int mi_spmm_fill_normal(float *d_out, int64_t n, uint64_t seed, uint64_t subsequence, float mean, float stddev,

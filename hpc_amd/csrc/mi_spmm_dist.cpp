@@ -35,6 +35,7 @@ struct mi_spmm_dist {
     int64_t N_total = 0;
     int exchange = kAllGather;
     bool rehearse = false;                     // run the exchange machinery even at world == 1 (one-GPU rehearsal)
+    int comm_stream_overlaps = -1, post_stream_overlaps = -1;   // mi_spmm_stream_create_concurrent's verdicts (-1: streams not made yet)
     bool external_barrier = false;             // peer2d without a communicator: the CALLER brackets every step with a cross-rank barrier
     std::vector<std::pair<int32_t, int32_t>> panels;
     int32_t rows_max = 0;
@@ -102,9 +103,16 @@ int ensure_streams(mi_spmm_dist *d)
     if (d->streams_ready) return 0;
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = highest priority
-    // exchange and re-layout at high priority: they must not queue behind a compute kernel that fills every CU
-    HIP_TRY(hipStreamCreateWithPriority(&d->s_comm, hipStreamNonBlocking, hi));
-    HIP_TRY(hipStreamCreateWithPriority(&d->s_post, hipStreamNonBlocking, hi));
+    // exchange and re-layout at high priority: they must not queue behind a compute kernel that fills every CU -- and they must run BESIDE it,
+    // which a stream does or does not depending on the hardware queue the runtime hands it: tested candidates (mi_spmm.h)
+    (void)lo; (void)hi;
+    {
+        void *sc = nullptr, *sp = nullptr;
+        MI_TRY(mi_spmm_stream_create_concurrent(&sc, 1, &d->comm_stream_overlaps));
+        d->s_comm = (hipStream_t)sc;
+        MI_TRY(mi_spmm_stream_create_concurrent(&sp, 1, &d->post_stream_overlaps));
+        d->s_post = (hipStream_t)sp;
+    }
     HIP_TRY(hipEventCreateWithFlags(&d->ev_start, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&d->ev_unpacked[i], hipEventDisableTiming));
     d->streams_ready = true;
@@ -561,6 +569,8 @@ int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *val
     else if (k == "rank") *value = d->rank;
     else if (k == "has_comm") *value = d->comm ? 1 : 0;
     else if (k == "external_barrier") *value = d->external_barrier ? 1 : 0;
+    else if (k == "comm_stream_overlaps") *value = d->comm_stream_overlaps;
+    else if (k == "post_stream_overlaps") *value = d->post_stream_overlaps;
     else if (k == "has_peers") *value = (int)d->peer_C.size() == d->world ? 1 : 0;
     else if (k == "staging_bytes") *value = (d->exchange == kPeer2D || d->exchange == kPeerStore) ? 0 : (int64_t)(2 * d->staging_elems * sizeof(float));
     else if (k == "bytes_sent_per_step") *value = moved;

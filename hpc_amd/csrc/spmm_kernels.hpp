@@ -1240,6 +1240,17 @@ __global__ __launch_bounds__(kBlockThreads) void fill_philox_kernel(uint32_t *__
     }
 }
 
+// ---- stream calibration: one wave that stays busy for `ticks` of the 100 MHz real-time counter (bounded) --------------------------------------
+// mi_spmm.hip concurrent_stream(): two of these, one on a candidate side stream and one on the null stream, take `ticks` together when the
+// two streams' hardware queues run side by side and 2 x `ticks` when they do not.
+__global__ void spin_kernel(unsigned long long ticks, unsigned int *sink)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned int n = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && n < (1u << 24)) { ++n; __builtin_amdgcn_s_sleep(8); }
+    if (sink && n == 0xffffffffu) *sink = n;       // (never: keeps the loop)
+}
+
 // ---- all-gather unpack: staging[G][rows][n_loc] -> C[rows][ldc] --------------
 template <int V>
 __global__ __launch_bounds__(kBlockThreads) void unpack_gathered(const float *__restrict__ staging,

@@ -218,6 +218,16 @@ int mi_spmm_unpack_gathered(const float *d_staging, float *d_C, int64_t rows,
                             int32_t n_ranks, int32_t n_loc, int64_t ldc,
                             void *stream);
 
+/* A stream whose kernels run BESIDE the null stream's, for callers that overlap work with run() (the multi-GPU step's exchange and
+ * re-layout streams; the handle's own hub stream is made this way).  The runtime maps a process's streams onto a few hardware queues
+ * per priority in creation order, and a queue that shares its command-processor pipe with the null stream's is served before or after
+ * it, not alongside: whether a new stream overlaps is a matter of how many streams the process made before.  So candidates are tested
+ * -- a 40 us spin kernel on the candidate and one on the null stream: ~65 us together when they run side by side, 90-120 when not --
+ * and the first that passes is returned (at most four are tried; the others are destroyed).  *overlaps_out (may be NULL) says whether
+ * the returned stream passed.  Synchronises (events): call at set-up time, not inside a step.  The caller destroys the stream
+ * (hipStreamDestroy).  high_priority != 0: the device's highest stream priority.  No reference counterpart (single stream, util.h:133-136). */
+int mi_spmm_stream_create_concurrent(void **stream_out, int high_priority, int *overlaps_out);
+
 /* Library/ABI identification. */
 int mi_spmm_abi_version(void);
 const char *mi_spmm_build_info(void);

@@ -58,6 +58,7 @@ def test_argument_checks_without_a_gpu():
     assert lib.mi_spmm_get_option(h, b"block_threads", ctypes.byref(v)) == 0 and v.value == 128
     assert lib.mi_spmm_destroy(h) == 0
     assert lib.mi_spmm_destroy(None) == 0
+    assert lib.mi_spmm_stream_create_concurrent(None, 1, None) == -1                              # no out pointer
 
 
 def test_product_never_touches_the_oracle():

@@ -797,6 +797,7 @@ def test_native_dist_step_world_one_rehearsal(device, oracle, exchange):
     exp = oracle.spmm_omp(ptr, idx, vals, B)
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
     assert (sh.get_option("staging_bytes") > 0) == (exchange not in ("peer2d", "peer_store"))
+    assert sh.get_option("comm_stream_overlaps") == 1 and sh.get_option("post_stream_overlaps") == 1      # the exchange and re-layout streams run beside the compute stream (tested candidates)
     # the two legs on their own (bench.py's breakdown: timing legs; with staging the panels share two buffers, so only
     # the staging-free exchange leaves a complete C behind)
     d_C.fill_(float("nan"))
@@ -949,6 +950,46 @@ def test_run_is_graph_capturable_and_stream_ordered(device, oracle, split, overl
     g.replay()
     torch.cuda.synchronize()
     assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
+
+
+def test_every_handle_gets_a_hub_stream_that_overlaps(device, oracle):
+    """The hub kernel's side stream is worth its fork only if its kernels run BESIDE the caller's.  Which hardware queue a new stream gets depends
+    on how many streams the process made before, and a queue on the caller's pipe is served first, not alongside (round 4: every other handle of
+    a process lost its overlap -- youtube-shaped N = 32: 0.32 ms instead of 0.17).  preprocess therefore tests its candidates with a pair of spin
+    kernels (mi_spmm_stream_create_concurrent) and keeps one that passes: six coexisting handles, every one of them with an overlapping stream and
+    the same step time; and the result is the oracle's whichever stream was picked."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    ptr, idx = synth.csr_powerlaw(200_000, 6.0, 40_000, seed=11, force_max=True)      # one 40 000-nonzero hub beside many short rows: the chain is the step
+    M, N = ptr.size - 1, 32
+    vals = synth.normal_f32(idx.size, 12)
+    B = synth.normal_f32(M * N, 13).reshape(M, N)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.empty((M, N), device=device)
+    ops, times = [], []
+    for i in range(6):
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N)
+        op.preprocess(d_B, d_C)
+        assert op.get_option("n_hub_rows") >= 1 and op.get_option("side_stream_overlaps") == 1, (i, op.get_option("side_stream_overlaps"))
+        for _ in range(3):
+            op.run(d_B, d_C)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(10):
+            op.run(d_B, d_C)
+        b.record()
+        torch.cuda.synchronize()
+        times.append(a.elapsed_time(b) / 10)
+        ops.append(op)
+    assert max(times) < 1.25 * min(times), times
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+    # the same maker through the C ABI (the multi-GPU step's exchange and re-layout streams come from it)
+    import ctypes as C
+    from hpc_amd import _lib
+    s, ov = C.c_void_p(None), C.c_int(-1)
+    assert _lib.load().mi_spmm_stream_create_concurrent(C.byref(s), 1, C.byref(ov)) == 0 and s.value and ov.value == 1
 
 
 @pytest.mark.parametrize("overlap", [0, 2])
