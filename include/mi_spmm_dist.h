@@ -100,7 +100,8 @@ int mi_spmm_dist_set_host_barrier(mi_spmm_dist *d, mi_spmm_dist_barrier_fn fn, v
 
 /* keys: "exchange" (0 allgather, 1 direct, 2 peer2d, 3 peer_store, 4 ipc_pull), "n_panels", "rehearse" (1: run the staging / collective /
  * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path), "external_barrier" (see above); read-only: "world", "rank", "has_comm",
- * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step" */
+ * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step", "comm_stream_overlaps" / "post_stream_overlaps" (1: the exchange /
+ * re-layout stream was tested to run beside the compute stream -- mi_spmm_stream_create_concurrent, mi_spmm.h; -1 before the first step) */
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);
 int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *value);
 
