@@ -397,7 +397,12 @@ static int ensure_side_streams(mi_spmm_handle *h)
     const bool long_step = bytes / 6e12 >= 200e-6;
     const bool exact_hubs = h->n_long > 0 && !h->split_long;
     h->overlap_on[0] = exact_hubs && (h->hub_overlap == 2 || (h->hub_overlap == 1 && (long_step || h->max_row_nnz >= 7000)));
-    h->overlap_on[1] = h->segment_overlap && h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
+    // The segment kernel gets a side stream of its own only where that was measured to pay (interleaved A/B over twelve graph shapes x three widths,
+    // profiles/r04_side_streams.txt): narrow B (N <= 64: both the rows kernel, 8 lanes per row, and the segment chains are latency-bound and fill
+    // each other's gaps -- citation- and wikikg2-shaped N = 32: -8 %) and no hub stream beside it.  Everywhere else a second stream is neutral to
+    // harmful (+0 .. +16 %: protein-shaped N = 32, with 1 696 hubs on their stream): the segment kernel then stays on the caller's stream.
+    const bool seg_side = h->segment_overlap == 1 || (h->segment_overlap == 2 && !h->overlap_on[0] && h->feat <= 64);
+    h->overlap_on[1] = seg_side && h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
     if (!(h->overlap_on[0] || h->overlap_on[1])) return MI_SPMM_OK;
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -564,7 +569,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->hub_slice = 0;
     h->hub_overlap = 1;
     h->side_priority = 3;
-    h->segment_overlap = 0;   // round 4: the segment kernel stays on the caller's stream (see "segment_overlap" in include/mi_spmm.h)
+    h->segment_overlap = 2;   // auto: a side stream for the segment kernel only where its longest chains are long (ensure_side_streams)
     h->long_chunk = 256;   // the reference's kBatchSize (spmm_opt.cu:6)
     h->rows_per_block = 0; // auto: one row per lane group (measured best at every N, profiles/r01_sweeps)
     h->xcd_remap = -1;     // auto (see run)
@@ -626,7 +631,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
     else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
     else if (k == "hub_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->hub_overlap = v; free_plan(h); }
-    else if (k == "segment_overlap") { h->segment_overlap = v ? 1 : 0; free_plan(h); }
+    else if (k == "segment_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->segment_overlap = v; free_plan(h); }
     else if (k == "flush_denormals") { h->ftz = v ? 1 : 0; free_plan(h); }       // (the block path is not used with it: preprocess again)
     else if (k == "side_priority") {
         if (v < 0 || v > 3) return MI_SPMM_EINVAL;

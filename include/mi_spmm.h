@@ -137,11 +137,11 @@ const char *mi_spmm_strerror(int code);
  *   "hub_overlap"         1 (default): the hub kernel runs on a handle-owned high-priority side stream forked from and joined
  *                         into the caller's stream inside every run call (events only), when the step is long enough to hide its
  *                         longest row behind the rows kernel (the fork costs ~20 us); 0: never; 2: always
- *   "segment_overlap"     0 (default): the segment kernel stays on the caller's stream, in front of the rows kernel.  1: it goes to
- *                         a second side stream under the "hub_overlap" rule (rounds 2-3).  Two side streams can land on ONE
- *                         hardware queue (the runtime maps streams to a few queues per priority): hub and segment kernels then run
- *                         one after the other and the step is slower than with no side stream at all; with one side stream that
- *                         cannot happen, and it measured equal or faster on every shape (profiles/r04_side_streams.txt)
+ *   "segment_overlap"     2 (default, auto): the segment kernel gets a second side stream (under the "hub_overlap" rule) only where an interleaved
+ *                         A/B measured a gain: N <= 64 and no hub stream in use (citation- / wikikg2-shaped kLen 32: -8 %); elsewhere it stays on
+ *                         the caller's stream, in front of the rows kernel (a second stream there is neutral to +16 %).  0: never.  1: always.
+ *                         Every side stream is TESTED to run beside the null stream before it is kept (mi_spmm_stream_create_concurrent):
+ *                         read-only "side_stream_overlaps" says whether the hub stream passed
  *   "side_priority"       bit 0 / bit 1: the hub / segment side stream is a high-priority stream (default 3)
  *   "flush_denormals"     0 (default): IEEE fp32 arithmetic, subnormals kept -- the canonical definition (spmm_ref.cu:10-14 with fma contraction).
  *                         1: the arithmetic of the reference's actual BUILD: nvcc --use_fast_math (CMakeLists.txt:46) implies -ftz=true, so
