@@ -51,6 +51,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 COLS_PER_GPU = 128
 
+# The contract: rank 0 prints ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout at
+# communicator set-up on this image), so main() points file descriptor 1 at stderr for the whole run and the line goes out through
+# a private duplicate of the original stdout: whatever else is printed, stdout carries the line and nothing else.
+_LINE_FD = None
+
+
+def claim_stdout():
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    data = (json.dumps(line) + "\n").encode()
+    fd = _LINE_FD if _LINE_FD is not None else 1
+    sys.stdout.flush()
+    while data:
+        n = os.write(fd, data)
+        data = data[n:]
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -199,13 +221,14 @@ class Watchdog:
                 elif self.rank == 0 and line is not None:
                     line["exchange_watchdog"] = {"fired_in": label, "note": "that section hung (no exception, no completion); this line is the "
                                                  "measurement in hand from before it; the process left with os._exit"}
-                    print(json.dumps(line), flush=True)
+                    emit_line(line)
                 os._exit(code)
 
 
 def main():
     args = parse()
     rank, world, local = dist_env(args)
+    claim_stdout()
     import torch
     import torch.distributed as dist
 
@@ -655,7 +678,7 @@ def main():
     if rank == 0:
         if wd is not None:
             wd.set_line(None)          # the final line is printed here, once
-        print(json.dumps(build_line()), flush=True)
+        emit_line(build_line())
     if multi:
         wd.arm("tear-down", wd_bound)   # nothing in hand any more: a hang here leaves with the watchdog's code, the line is out
         del sharded
@@ -856,8 +879,8 @@ def sweep(args, op, step, M, N, nnz):
         rows.append((ms, c))
     rows.sort()
     for ms, c in rows:
-        print(json.dumps({"sweep": dict(zip(keys, c)), "ms_median": round(ms, 4), "ms_min": round(min(results[c]), 4),
-                          "GBs_alg": round(model["bytes_alg"] / ms / 1e6, 1), "GFLOPs": round(2.0 * nnz * N / ms / 1e6, 1)}), flush=True)
+        emit_line({"sweep": dict(zip(keys, c)), "ms_median": round(ms, 4), "ms_min": round(min(results[c]), 4),
+                   "GBs_alg": round(model["bytes_alg"] / ms / 1e6, 1), "GFLOPs": round(2.0 * nnz * N / ms / 1e6, 1)})
 
 
 if __name__ == "__main__":

@@ -16,9 +16,10 @@ def _run(*extra, **env_extra):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--M", "65536", "--steps", "3", "--warmup", "1", *extra],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "exactly ONE JSON line"
-    return json.loads(lines[0])
+    # stdout carries the contract line and NOTHING else (RCCL's version banner, which the library prints to stdout, included: bench.py
+    # points fd 1 at stderr and writes the line through a private duplicate of the original stdout)
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), repr(r.stdout[:200])
+    return json.loads(r.stdout)
 
 
 def test_single_gpu_line():
