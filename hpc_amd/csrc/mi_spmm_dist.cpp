@@ -101,11 +101,8 @@ void free_staging(mi_spmm_dist *d)
 int ensure_streams(mi_spmm_dist *d)
 {
     if (d->streams_ready) return 0;
-    int lo = 0, hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = highest priority
     // exchange and re-layout at high priority: they must not queue behind a compute kernel that fills every CU -- and they must run BESIDE it,
     // which a stream does or does not depending on the hardware queue the runtime hands it: tested candidates (mi_spmm.h)
-    (void)lo; (void)hi;
     {
         void *sc = nullptr, *sp = nullptr;
         MI_TRY(mi_spmm_stream_create_concurrent(&sc, 1, &d->comm_stream_overlaps));
