@@ -13,4 +13,9 @@ for n in "${names[@]}"; do
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -I "$root/hpc_amd/csrc" -I "$root/include" \
         "$here/$n.hip" $extra -o "$here/build/$n"
     echo "built $here/build/$n"
+    if [ "$n" = hub_micro ] && [ -n "$HUB_MICRO_VARIANTS" ]; then      # counter-attribution builds (see make_hub_micro.py)
+        for v in NO_B128 NO_B32 NO_BPERM; do
+            /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -D$v -I "$root/hpc_amd/csrc" -I "$root/include" "$here/$n.hip" -o "$here/build/${n}_$v"
+        done
+    fi
 done
