@@ -100,7 +100,7 @@ def test_multi_gpu_candidate_that_hangs_still_yields_the_line_in_hand():
     """A schedule that neither finishes nor throws (forced: MI_SPMM_FORCE_HANG_EXCHANGE) must not cost the measurement: the
     per-rank watchdog prints the all-gather line it has in hand, says what hung, and the process leaves (exit code 0: the
     line is a complete measurement)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", MI_SPMM_FORCE_HANG_EXCHANGE="peer2d", MI_SPMM_WATCHDOG_S="45")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", MI_SPMM_FORCE_HANG_EXCHANGE="peer2d", MI_SPMM_WATCHDOG_S="25")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--M", "65536", "--steps", "3", "--warmup", "1", "--rehearse-multi",
                         "--no-cpu-baseline", "--panels", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -154,7 +154,7 @@ def test_driver_launch_line_two_ranks_sharing_the_gpu():
 def test_driver_launch_line_two_ranks_with_a_candidate_that_hangs():
     """The same two-rank launch with the candidate schedule hanging on BOTH ranks: each rank's watchdog fires, rank 0 prints
     the peer2d line it has in hand, torch.distributed.run sees two clean exits."""
-    env = dict(os.environ, MI_SPMM_SHARE_GPU="1", MI_SPMM_FORCE_HANG_EXCHANGE="peer_store", MI_SPMM_WATCHDOG_S="45")
+    env = dict(os.environ, MI_SPMM_SHARE_GPU="1", MI_SPMM_FORCE_HANG_EXCHANGE="peer_store", MI_SPMM_WATCHDOG_S="25")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--M", "65536"],
