@@ -1039,9 +1039,10 @@ void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 g
 }
 
 template <bool WIDE>
-void launch_hub(int sw, const HubArgs &a, dim3 grid, hipStream_t s)
+void launch_hub(int sw, bool excl, const HubArgs &a, dim3 grid, hipStream_t s)
 {
-    if (sw == 16) hipLaunchKernelGGL((spmm_hub<16, WIDE>), grid, dim3(64 * (1 + HubCfg<16>::L)), 0, s, a);
+    if (sw == 16 && excl) hipLaunchKernelGGL((spmm_hub<16, WIDE, true>), grid, dim3(64 * (1 + HubCfg<16>::L)), 0, s, a);
+    else if (sw == 16) hipLaunchKernelGGL((spmm_hub<16, WIDE>), grid, dim3(64 * (1 + HubCfg<16>::L)), 0, s, a);
     else if (sw == 64) hipLaunchKernelGGL((spmm_hub<64, WIDE>), grid, dim3(64 * (1 + HubCfg<64>::L)), 0, s, a);
     else hipLaunchKernelGGL((spmm_hub<32, WIDE>), grid, dim3(64 * (1 + HubCfg<32>::L)), 0, s, a);
 }
@@ -1153,11 +1154,14 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         // 0.84 -> 0.72 ms; where the hub rows are many rather than one long, 32 is faster: R-MAT N = 32 0.47 vs 0.56;
         // profiles/r03_hub_experiments.txt)
         int sw = (int)h->hub_slice;
+        bool excl = false;         // the chain-bound case: the hub workgroups keep their CUs to themselves (spmm_kernels.hpp EXCL)
         if (sw <= 0) {
             const double step_s = ((double)h->nnz * (4.0 * full.N + 8.0) + 4.0 * (double)h->num_v * full.N) / 6e12;
             // (round 4, new chain loop: 16 and 32 are within 1-3 % of each other on chain-bound graphs up to N = 128; at N = 256 the 16 workgroups
             //  of a row cost more than they save: am-shaped 1.164 -> 1.119 ms with 32; 64 loses everywhere it is the chain that counts)
-            sw = (full.N <= 16 || (full.N <= 128 && (double)h->max_row_nnz * 3.3e-9 > 0.5 * step_s)) ? 16 : 32;
+            const bool chain_bound = full.N <= 128 && (double)h->max_row_nnz * 3.3e-9 > 0.5 * step_s;
+            sw = (full.N <= 16 || chain_bound) ? 16 : 32;
+            excl = chain_bound;
         }
         const bool wide_hub = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
                                 ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));
@@ -1170,7 +1174,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
             const int fr = side_stream(h, 0, s, &hs);
             if (fr != 0) return fr;
         }
-        if (wide_hub) launch_hub<true>(sw, ha, hgrid, hs); else launch_hub<false>(sw, ha, hgrid, hs);
+        if (wide_hub) launch_hub<true>(sw, excl, ha, hgrid, hs); else launch_hub<false>(sw, excl, ha, hgrid, hs);
         ++launches;
     }
     if (h->n_chunks > 0) {

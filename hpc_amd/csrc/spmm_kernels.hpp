@@ -507,7 +507,7 @@ __device__ __forceinline__ void hub_flag_store(int *p, int v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SW, bool WIDE>
+template <int SW, bool WIDE, bool EXCL = false>
 __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 {
     typedef HubCfg<SW> K;
@@ -515,6 +515,12 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
     __shared__ __attribute__((aligned(16))) float ring[K::LDS_BYTES / 4];
     __shared__ int flags[16];                                   // [0] pub: stages 0 .. pub-1 are in the ring (INT_MAX once the row's last one is); [L] done: stages consumed
     apply_ftz(a.flags);
+    // EXCL: the workgroup keeps its CU's four SIMDs to itself.  A chain wave that shares its SIMD with the rows kernel's waves shares the SIMD's
+    // issue slots with them -- beside a rows kernel that fills the machine a stage takes ~680 cycles instead of 495 -- and nothing but registers
+    // keeps other waves off a SIMD: touching a255 makes the kernel's footprint 135 + 256 registers, one wave per SIMD.  Used only where ONE row's
+    // chain is the step (mi_spmm.hip: the rule that picks 16-column slices): am-shaped N = 128 0.67 -> 0.61 ms, N = 32 0.48 -> 0.47; with many
+    // hubs it would cost throughput (a CU per workgroup) and is not used.
+    if (EXCL) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;
