@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 (3, 4) gloo runs of the column-sharded driver, both exchange schedules.
+"""The N>1 path on CPU: world_size-2 (3, 4, 8) gloo runs of the column-sharded driver, both exchange schedules.
 
 The host logic under test is hpc_amd/dist.py (column blocks, row panels, all-gather, unpack).
 The device pieces are replaced by test doubles: the local operator is the oracle restricted to
@@ -91,7 +91,7 @@ def _worker(rank, world, port, M, n_loc, n_panels, q, exchange="allgather"):
 
 @pytest.mark.parametrize("world,M,n_loc,n_panels,exchange", [(2, 1000, 16, 3, "allgather"), (2, 777, 5, 1, "allgather"), (3, 600, 8, 4, "allgather"),
                                                               (2, 1000, 16, 3, "direct"), (3, 600, 8, 4, "direct"), (4, 515, 4, 2, "direct"),
-                                                              (3, 600, 8, 4, "tune")])
+                                                              (3, 600, 8, 4, "tune"), (8, 530, 4, 3, "allgather"), (8, 530, 4, 3, "direct")])
 def test_gloo_column_sharded_matches_single_process(world, M, n_loc, n_panels, exchange):
     import torch.multiprocessing as mp
     from oracle import oracle

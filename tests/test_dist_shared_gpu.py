@@ -213,10 +213,12 @@ def test_native_peer2d_exchange_between_ranks_sharing_one_gpu(world, M, n_loc, n
 
 
 @pytest.mark.parametrize("exchange", ["peer2d", "peer_store"])
-@pytest.mark.parametrize("world,kind", [(2, "uniform"), (4, "powerlaw")])
+@pytest.mark.parametrize("world,kind", [(2, "uniform"), (4, "powerlaw"), (8, "powerlaw")])
 def test_ranks_in_one_process_through_peer_pointers(exchange, world, kind):
     """mi_spmm_dist_set_peer_pointers: a host that drives every rank from one process hands the peers' C_full in as plain device
-    pointers (no IPC).  Four rank objects on the one GPU, hub rows included: every C_full equals the single-operator C bit for bit."""
+    pointers (no IPC).  Up to eight rank objects on the one GPU, hub rows included: every C_full equals the single-operator C bit for
+    bit.  World 8 is the north star's node: seven peers fill the kernels' PeerOut table (peer_store) and the seven push streams
+    (peer2d) -- the only place the full table is exercised without an 8-GPU node."""
     import torch
 
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
