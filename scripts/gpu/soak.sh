@@ -1,13 +1,19 @@
 #!/bin/bash
-# a soak of the three fuzz tests on a seed other than the suite's (MI_SPMM_FUZZ_SEED), after the whole -m gpu suite has passed
-# usage: scripts/gpu/soak.sh [seed] [shape cases] [hub cases] [block cases]
+# a soak of the three fuzz tests on seeds other than the suite's (MI_SPMM_FUZZ_SEED); with SUITE=1 the whole -m gpu suite runs first
+# usage: [SUITE=1] scripts/gpu/soak.sh "seed seed ..." [shape cases] [hub cases] [block cases]
 set -o pipefail
 out=gpurun_out; mkdir -p $out
-seed=${1:-11}; shapes=${2:-1500}; hubs=${3:-300}; blocks=${4:-300}
-timeout -k 10 700 python -m pytest tests -x -q -m gpu > $out/soak_suite.log 2>&1; rc=$?
-tail -5 $out/soak_suite.log
-[ $rc -ne 0 ] && exit $rc
-MI_SPMM_FUZZ_SEED=$seed MI_SPMM_FUZZ_CASES=$shapes MI_SPMM_HUB_FUZZ_CASES=$hubs MI_SPMM_BLOCK_FUZZ_CASES=$blocks \
-  timeout -k 10 420 python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "fuzz or random_lengths" > $out/soak_fuzz_seed$seed.log 2>&1; rc=$?
-tail -5 $out/soak_fuzz_seed$seed.log
-exit $rc
+seeds=${1:-11}; shapes=${2:-1500}; hubs=${3:-300}; blocks=${4:-300}
+if [ "${SUITE:-0}" = 1 ]; then
+  timeout -k 10 700 python -m pytest tests -x -q -m gpu > $out/soak_suite.log 2>&1; rc=$?
+  tail -5 $out/soak_suite.log
+  [ $rc -ne 0 ] && exit $rc
+fi
+for seed in $seeds; do
+  export MI_SPMM_FUZZ_SEED=$seed MI_SPMM_FUZZ_CASES=$shapes MI_SPMM_HUB_FUZZ_CASES=$hubs MI_SPMM_BLOCK_FUZZ_CASES=$blocks
+  echo "seed $seed: $shapes shape cases, $hubs hub cases, $blocks block cases"
+  timeout -k 10 500 python -m pytest tests/test_parity_gpu.py -x -q -m gpu --durations=3 -k "fuzz or random_lengths" > $out/soak_fuzz_seed$seed.log 2>&1; rc=$?
+  tail -12 $out/soak_fuzz_seed$seed.log
+  [ $rc -ne 0 ] && exit $rc
+done
+exit 0
