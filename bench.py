@@ -180,6 +180,7 @@ class Watchdog:
         import threading
 
         self.rank = rank
+        self.t0 = time.monotonic()
         self.lock = threading.Lock()
         self.deadline, self.label, self.line, self.measured, self.printed = None, None, None, False, False
         self.thread = threading.Thread(target=self._loop, daemon=True, name="bench-watchdog")
@@ -197,6 +198,8 @@ class Watchdog:
             self.measured = True
 
     def arm(self, label, seconds):
+        # one stderr line per guarded section and rank: the record of a run that hangs says how far each rank got
+        print(f"[bench] rank {self.rank}: +{time.monotonic() - self.t0:.1f}s {label}", file=sys.stderr, flush=True)
         with self.lock:
             self.label, self.deadline = label, time.monotonic() + float(seconds)
 
@@ -213,6 +216,13 @@ class Watchdog:
                 label, line = self.label, self.line
                 print(f"[bench] rank {self.rank}: watchdog: '{label}' neither finished nor threw within its bound; "
                       f"{'printing the line in hand and ' if (line is not None and self.rank == 0) else ''}leaving", file=sys.stderr, flush=True)
+                try:                               # where every thread of this rank stands (Python frames), for the record of the run
+                    import faulthandler
+
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    sys.stderr.flush()
+                except Exception:
+                    pass
                 code = int(os.environ.get("MI_SPMM_WATCHDOG_EXIT", "0"))
                 if not self.measured:
                     code = code or 3               # nothing measured yet: this run has no result
@@ -268,7 +278,11 @@ def main():
     nnz = int(idx.size)
     t_gen = time.time() - t_gen
     d_ptr, d_idx, d_val, d_B = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals, B_loc))
-    d_Cfull = torch.full((M, n_total), float("nan"), dtype=torch.float32, device=dev)
+    if multi:      # peers map this buffer (peer2d / peer_store): allocated at a size HIP IPC can open (C1 on 4 GPUs: 2 GiB -> 4 GiB)
+        from hpc_amd.dist import alloc_c_full
+        d_Cfull = alloc_c_full(M, n_total, dev, fill=float("nan"))
+    else:
+        d_Cfull = torch.full((M, n_total), float("nan"), dtype=torch.float32, device=dev)
 
     op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), n_loc)
     for kv in args.opt:
@@ -286,6 +300,11 @@ def main():
     def barrier():
         if multi:
             dist.barrier()
+
+    def trace(what):
+        """N > 1: one stderr line per set-up stage and rank (stdout carries the contract line only), so that the record of a run that hangs says how far each rank got."""
+        if multi:
+            print(f"[bench] rank {rank}: +{time.monotonic() - wd.t0:.1f}s {what}", file=sys.stderr, flush=True)
 
     def agree(x, red):
         v = torch.tensor([float(x)], dtype=torch.float64, device=dev if not share else "cpu")
@@ -321,10 +340,12 @@ def main():
                 raise RuntimeError("MI_SPMM_FORCE_PY_DIST=1")
             sharded = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, world, rank), n_panels=args.panels,
                                               exchange="allgather", rehearse=args.rehearse_multi)
+            trace("step object created (streams, staging)")
             if share:
                 sharded.set_option("external_barrier", 1)   # step() below brackets every run with synchronize + dist.barrier
             else:
                 sharded.init_comm()    # our own RCCL communicator (unique id broadcast over torch.distributed)
+                trace("communicator up")
         except Exception as e:
             print(f"[bench] rank {rank}: native multi-GPU step unavailable: {e!r}", file=sys.stderr, flush=True)
             native_ok = 0.0
@@ -344,6 +365,7 @@ def main():
             sharded.set_exchange(safe)
             if safe in needs_peers:
                 sharded.set_peers(d_Cfull)
+                trace("peers' C mapped")
         wd.disarm()
     exchange = safe if multi else None
 

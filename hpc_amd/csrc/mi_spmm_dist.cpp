@@ -12,6 +12,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +39,7 @@ struct mi_spmm_dist {
     bool rehearse = false;                     // run the exchange machinery even at world == 1 (one-GPU rehearsal)
     int comm_stream_overlaps = -1, post_stream_overlaps = -1;   // mi_spmm_stream_create_concurrent's verdicts (-1: streams not made yet)
     bool external_barrier = false;             // peer2d without a communicator: the CALLER brackets every step with a cross-rank barrier
+    bool ipc_any_size = false;                 // export allocations of any size (see mi_spmm_dist_ipc_exportable_bytes)
     std::vector<std::pair<int32_t, int32_t>> panels;
     int32_t rows_max = 0;
     // streams / events (created on first use, on the device current at that time)
@@ -70,6 +73,22 @@ struct mi_spmm_dist {
 namespace {
 
 bool good(const mi_spmm_dist *d) { return d && d->magic == 0x4d494453u; }
+
+// hipIpcOpenMemHandle never returns for an allocation whose SIZE has bit 31 set (2 GiB <= size mod 4 GiB): measured with the HIP
+// runtime of the torch 2.10+rocm7.0 wheel in dmabuf IPC mode (HSA_ENABLE_IPC_MODE_LEGACY=0), two processes on one MI355X --
+// 1, 1.5, 4 and 5 GiB open in under a millisecond and read back right to their last byte; 2, 2.002, 3 and 6 GiB hang in the
+// importer (scripts/debug/ipc_open_probe.py, profiles/r04_ipc_open_sizes.txt).  An exporter cannot un-hang its peers, so it refuses.
+bool ipc_size_ok(size_t size) { return ((size >> 31) & 1u) == 0; }
+
+int refuse_ipc_size(const char *where, size_t size)
+{
+    if (const char *dbg = std::getenv("MI_SPMM_DEBUG"))
+        if (dbg[0] == '1')
+            std::fprintf(stderr, "%s: the allocation is %zu bytes; hipIpcOpenMemHandle hangs on sizes with bit 31 set -- allocate %lld bytes "
+                                 "(mi_spmm_dist_ipc_exportable_bytes) or set \"ipc_any_size\"\n", where, size,
+                         (long long)mi_spmm_dist_ipc_exportable_bytes((int64_t)size));
+    return MI_SPMM_EUNSUPPORTED;
+}
 
 void make_panels(mi_spmm_dist *d)
 {
@@ -148,8 +167,10 @@ int ensure_staging(mi_spmm_dist *d)
     const size_t need = (size_t)d->world * (size_t)d->rows_max * (size_t)d->n_loc;
     if (d->staging[0] && d->staging_elems >= need) return 0;
     free_staging(d);
+    // allocated at a size the runtime can export (ipc_pull maps the peers' staging buffers; mi_spmm_dist_ipc_exportable_bytes)
+    const size_t bytes = (size_t)mi_spmm_dist_ipc_exportable_bytes((int64_t)((need ? need : 1) * sizeof(float)));
     for (int i = 0; i < 2; ++i)
-        if (hipMalloc((void **)&d->staging[i], (need ? need : 1) * sizeof(float)) != hipSuccess) { free_staging(d); return MI_SPMM_ENOMEM; }
+        if (hipMalloc((void **)&d->staging[i], bytes) != hipSuccess) { free_staging(d); return MI_SPMM_ENOMEM; }
     d->staging_elems = need;
     d->unpacked_valid[0] = d->unpacked_valid[1] = false;
     return 0;
@@ -449,6 +470,7 @@ int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, in
     hipDeviceptr_t base = nullptr;
     size_t size = 0;
     HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d_C_full));   // the caller's allocator may sub-allocate
+    if (!d->ipc_any_size && !ipc_size_ok(size)) return refuse_ipc_size("mi_spmm_dist_export_c", size);
     hipIpcMemHandle_t hnd;
     HIP_TRY(hipIpcGetMemHandle(&hnd, base));
     std::memcpy(handle_out, &hnd, sizeof(hnd));
@@ -492,6 +514,7 @@ int mi_spmm_dist_export_staging(mi_spmm_dist *d, void *handles_out, int64_t *off
         hipDeviceptr_t base = nullptr;
         size_t size = 0;
         HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d->staging[b]));
+        if (!d->ipc_any_size && !ipc_size_ok(size)) return refuse_ipc_size("mi_spmm_dist_export_staging", size);
         hipIpcMemHandle_t hnd;
         HIP_TRY(hipIpcGetMemHandle(&hnd, base));
         std::memcpy((char *)handles_out + (size_t)b * sizeof(hnd), &hnd, sizeof(hnd));
@@ -544,6 +567,7 @@ int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t v)
     if (k == "exchange") { if (v < 0 || v > 4) return MI_SPMM_EINVAL; d->exchange = (int)v; }
     else if (k == "rehearse") d->rehearse = v != 0;
     else if (k == "external_barrier") d->external_barrier = v != 0;
+    else if (k == "ipc_any_size") d->ipc_any_size = v != 0;
     else if (k == "n_panels") {
         if (v < 1 || v > (1 << 20)) return MI_SPMM_EINVAL;
         (void)hipDeviceSynchronize();   // staging buffers of a step in flight
@@ -566,6 +590,7 @@ int mi_spmm_dist_get_option(const mi_spmm_dist *d, const char *key, int64_t *val
     else if (k == "rank") *value = d->rank;
     else if (k == "has_comm") *value = d->comm ? 1 : 0;
     else if (k == "external_barrier") *value = d->external_barrier ? 1 : 0;
+    else if (k == "ipc_any_size") *value = d->ipc_any_size ? 1 : 0;
     else if (k == "comm_stream_overlaps") *value = d->comm_stream_overlaps;
     else if (k == "post_stream_overlaps") *value = d->post_stream_overlaps;
     else if (k == "has_peers") *value = (int)d->peer_C.size() == d->world ? 1 : 0;
@@ -589,6 +614,13 @@ int mi_spmm_dist_run_compute_only(mi_spmm_dist *d, const float *d_B_loc, float *
 int mi_spmm_dist_run_exchange_only(mi_spmm_dist *d, float *d_C_full, void *stream)
 {
     return step(d, nullptr, d_C_full, (hipStream_t)stream, false, true);
+}
+
+int64_t mi_spmm_dist_ipc_exportable_bytes(int64_t nbytes)
+{
+    if (nbytes < 0) return MI_SPMM_EINVAL;
+    const uint64_t n = (uint64_t)nbytes;
+    return ((n >> 31) & 1u) ? (int64_t)(((n >> 32) + 1) << 32) : nbytes;      // bit 31 set: up to the next multiple of 4 GiB
 }
 
 const char *mi_spmm_dist_strerror(int code)

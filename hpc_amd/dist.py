@@ -253,6 +253,7 @@ _DIST_SIGNATURES = {
     "mi_spmm_dist_comm_init": (_C.c_int, [_P, _P]),
     "mi_spmm_dist_set_comm": (_C.c_int, [_P, _P]),
     "mi_spmm_dist_export_c": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_ipc_exportable_bytes": (_C.c_int64, [_C.c_int64]),
     "mi_spmm_dist_set_peers": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_set_peer_pointers": (_C.c_int, [_P, _P, _P]),
     "mi_spmm_dist_export_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
@@ -300,6 +301,29 @@ def load_dist():
 def _dcheck(code, where):
     if code != 0:
         raise MiSpmmDistError(code, where)
+
+
+def ipc_exportable_bytes(nbytes):
+    """mi_spmm_dist_ipc_exportable_bytes: the allocation size to use for a buffer of nbytes that peers will map through HIP IPC
+    (hipIpcOpenMemHandle hangs on allocations whose size has bit 31 set: such sizes go up to the next multiple of 4 GiB)."""
+    return int(load_dist().mi_spmm_dist_ipc_exportable_bytes(int(nbytes)))
+
+
+def alloc_c_full(M, n_total, device, fill=None):
+    """A row-major M x n_total fp32 C_full whose ALLOCATION the peers can map (peer2d / peer_store): a view of the front of a flat
+    buffer of ipc_exportable_bytes(4 * M * n_total) bytes, in a block of its own (the caching allocator may otherwise hand out
+    part of a larger cached block of any size).  C1 on four GPUs is exactly 2 GiB: allocated as 4 GiB."""
+    import torch
+
+    need = 4 * int(M) * int(n_total)
+    nbytes = ipc_exportable_bytes(need)
+    if nbytes != need:
+        torch.cuda.empty_cache()             # no cached block of another size to be re-used for this request
+    flat = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    C = flat[: int(M) * int(n_total)].view(int(M), int(n_total))
+    if fill is not None:
+        C.fill_(fill)
+    return C
 
 
 class NativeColumnShardedSpMM:

@@ -81,6 +81,14 @@ int mi_spmm_dist_set_comm(mi_spmm_dist *d, void *nccl_comm);
  * allocation), all-gather handles and offsets on the host side, hand the tables in.  handles: world x 64 bytes,
  * offsets: world x int64; the rank's own entry is ignored.  Re-call when C_full changes. */
 int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, int64_t *offset_out);
+
+/* Allocation sizes and HIP IPC.  hipIpcOpenMemHandle does not return for an allocation whose size has bit 31 set (2 GiB <= size
+ * mod 4 GiB; measured in dmabuf IPC mode, round 4: 2 and 3 GiB hang in the importer, 1, 1.5, 4 and 5 GiB open at once), and an
+ * exporter cannot un-hang its peers: mi_spmm_dist_export_c / _export_staging return MI_SPMM_EUNSUPPORTED for such an allocation
+ * (the one d_C_full lies in: hipMemGetAddressRange) unless "ipc_any_size" is set.  A host that wants peer2d / peer_store with
+ * M x N_total x 4 in that range (C1 on four GPUs: exactly 2 GiB) allocates C_full with this many bytes instead:
+ * nbytes itself when it can be exported, else the next multiple of 4 GiB.  The library's own staging buffers are sized that way. */
+int64_t mi_spmm_dist_ipc_exportable_bytes(int64_t nbytes);
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
 /* The same table for a host that drives several ranks from ONE process (one thread or object per GPU, peer access enabled by
@@ -99,7 +107,7 @@ typedef void (*mi_spmm_dist_barrier_fn)(void *ctx);
 int mi_spmm_dist_set_host_barrier(mi_spmm_dist *d, mi_spmm_dist_barrier_fn fn, void *ctx);
 
 /* keys: "exchange" (0 allgather, 1 direct, 2 peer2d, 3 peer_store, 4 ipc_pull), "n_panels", "rehearse" (1: run the staging / collective /
- * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path), "external_barrier" (see above); read-only: "world", "rank", "has_comm",
+ * re-layout machinery even at world == 1 -- the one-GPU rehearsal of the N > 1 path), "external_barrier" (see above), "ipc_any_size" (1: export allocations whatever their size, see mi_spmm_dist_ipc_exportable_bytes); read-only: "world", "rank", "has_comm",
  * "has_peers", "staging_bytes", "bytes_sent_per_step", "bytes_received_per_step", "comm_stream_overlaps" / "post_stream_overlaps" (1: the exchange /
  * re-layout stream was tested to run beside the compute stream -- mi_spmm_stream_create_concurrent, mi_spmm.h; -1 before the first step) */
 int mi_spmm_dist_set_option(mi_spmm_dist *d, const char *key, int64_t value);

@@ -146,6 +146,23 @@ def test_dist_argument_checks_without_a_gpu():
     _lib.load().mi_spmm_destroy(h)
 
 
+def test_ipc_exportable_sizes_rule():
+    """Allocation sizes HIP IPC can open (include/mi_spmm_dist.h): bit 31 of the size must be clear, sizes that have it set go up
+    to the next multiple of 4 GiB (hipIpcOpenMemHandle hangs on 2, 3 and 6 GiB and opens 1, 1.5, 4 and 5 GiB: profiles/r04_ipc_open_sizes.txt)."""
+    from hpc_amd import dist
+
+    G = 1 << 30
+    f = dist.ipc_exportable_bytes
+    assert [f(0), f(1), f(G), f(2 * G - 1), f(3 * G // 2)] == [0, 1, G, 2 * G - 1, 3 * G // 2]
+    assert [f(2 * G), f(2 * G + 1), f(3 * G), f(4 * G - 1)] == [4 * G] * 4
+    assert [f(4 * G), f(5 * G), f(6 * G - 1)] == [4 * G, 5 * G, 6 * G - 1]
+    assert [f(6 * G), f(7 * G + 5), f(8 * G)] == [8 * G, 8 * G, 8 * G]
+    assert f(-1) == -1
+    # what bench.py allocates as C_full for C1 at 128 columns per GPU: M = 2^20 rows x (128 x G) columns x 4 bytes
+    assert [f(4 * (1 << 20) * 128 * g) // G for g in (1, 2, 3, 4, 6, 8)] == [0, 1, 1, 4, 4, 4]
+    assert [f(4 * (1 << 20) * 128 * g) for g in (2, 4, 8)] == [G, 4 * G, 4 * G]
+
+
 def test_profiles_text_files_are_sane():
     """Evidence files under profiles/ are small and not a paragraph repeated thousands of times (round 2 lost one that way:
     an append script iterated over the characters of the old text)."""

@@ -232,3 +232,50 @@ def test_ranks_in_one_process_through_peer_pointers(exchange, world, kind):
     for r, c in enumerate(C):
         assert not torch.isnan(c).any(), r
         assert torch.equal(c.view(torch.int32), C_one.view(torch.int32)), r
+
+
+def test_export_refuses_allocation_sizes_that_hang_hip_ipc():
+    """hipIpcOpenMemHandle never returns for an allocation whose size has bit 31 set (profiles/r04_ipc_open_sizes.txt: the N = 4
+    rehearsal of bench.py's launch line hung on its 2 GiB C_full).  The exporter refuses such an allocation at once
+    (MI_SPMM_EUNSUPPORTED) instead of leaving its peers in a call that never returns; hpc_amd.dist.alloc_c_full allocates the same
+    M x N_total in a block the peers can open; "ipc_any_size" switches the check off."""
+    import ctypes
+
+    import torch
+
+    from hpc_amd import CSR, SpMMOpt, synth
+    from hpc_amd.dist import IPC_HANDLE_BYTES, NativeColumnShardedSpMM, ShardLayout, alloc_c_full, ipc_exportable_bytes, load_dist
+
+    dev = torch.device("cuda", 0)
+    M, n_loc = 4096, 32
+    ptr, idx = synth.csr_uniform(M, 0, 20, seed=3)
+    vals = synth.normal_f32(idx.size, 4)
+    d_ptr, d_idx, d_val = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals))
+    B = torch.zeros(M, n_loc, device=dev)
+    C = torch.zeros(M, n_loc, device=dev)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), n_loc)
+    op.preprocess(B, C)
+    sh = NativeColumnShardedSpMM(op, ShardLayout(M, n_loc, 1, 0), n_panels=2, exchange="peer2d")
+    lib = load_dist()
+    h = (ctypes.c_char * IPC_HANDLE_BYTES)()
+    off = ctypes.c_int64(-1)
+
+    def export(t):
+        return lib.mi_spmm_dist_export_c(sh._d, ctypes.c_void_p(t.data_ptr()), h, ctypes.byref(off))
+
+    torch.cuda.empty_cache()
+    bad = torch.empty(1 << 29, dtype=torch.float32, device=dev)              # 2 GiB: C1's C_full on four GPUs
+    assert export(bad) == -5
+    sh.set_option("ipc_any_size", 1)
+    assert export(bad) == 0 and off.value == 0                               # the handle alone is harmless; opening it is what hangs
+    sh.set_option("ipc_any_size", 0)
+    del bad
+    torch.cuda.empty_cache()
+    good = alloc_c_full(1 << 20, 512, dev)                                   # the same 2 GiB of C inside a 4 GiB block
+    assert good.shape == (1 << 20, 512) and good.is_contiguous()
+    assert ipc_exportable_bytes(4 * good.numel()) == 1 << 32
+    assert export(good) == 0 and off.value == 0
+    small = alloc_c_full(1000, 256, dev, fill=float("nan"))                  # sizes that need no padding are allocated as they are
+    assert torch.isnan(small).all() and export(small) == 0
+    del good, small
+    torch.cuda.empty_cache()
