@@ -536,10 +536,17 @@ def main():
             sharded.set_exchange(name_)
             if name_ in needs_peers:
                 sharded.set_peers(d_Cfull)
-            step()
-            torch.cuda.synchronize()
         except Exception as e:                                    # every rank still takes part in the agreement below
             print(f"[bench] rank {rank}: exchange {name_} unavailable: {e!r}", file=sys.stderr, flush=True)
+            ok = 0.0
+        # agreed BEFORE the first step: a step holds a cross-rank barrier, which a rank whose set-up failed would never enter
+        if agree(ok, dist.ReduceOp.MIN) < 1.0:
+            return False, None
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:
+            print(f"[bench] rank {rank}: exchange {name_}: first step failed: {e!r}", file=sys.stderr, flush=True)
             ok = 0.0
         if agree(ok, dist.ReduceOp.MIN) < 1.0:
             return False, None

@@ -393,13 +393,18 @@ class NativeColumnShardedSpMM:
         L = self.layout
         h = (_C.c_char * IPC_HANDLE_BYTES)()
         off = _C.c_int64(0)
-        _dcheck(self._lib.mi_spmm_dist_export_c(self._d, _P(C_full.data_ptr()), h, _C.byref(off)), "mi_spmm_dist_export_c")
-        mine = (bytes(h), int(off.value))
+        # a rank that cannot export (e.g. an allocation size HIP IPC cannot open: mi_spmm_dist_ipc_exportable_bytes) still takes part
+        # in the all-gather, and then EVERY rank raises: no rank is left waiting in a collective the failing one never entered
+        code = self._lib.mi_spmm_dist_export_c(self._d, _P(C_full.data_ptr()), h, _C.byref(off))
+        mine = (bytes(h), int(off.value)) if code == 0 else None
         if L.world > 1:
             table = [None] * L.world
             dist.all_gather_object(table, mine, group=self.group)
         else:
             table = [mine]
+        _dcheck(code, "mi_spmm_dist_export_c")
+        if any(t is None for t in table):
+            raise MiSpmmDistError(-5, f"mi_spmm_dist_export_c on rank(s) {[q for q, t in enumerate(table) if t is None]}")
         handles = (_C.c_char * (IPC_HANDLE_BYTES * L.world))()
         offsets = (_C.c_int64 * L.world)()
         for q, (hb, ob) in enumerate(table):
@@ -421,13 +426,16 @@ class NativeColumnShardedSpMM:
         L = self.layout
         h = (_C.c_char * (2 * IPC_HANDLE_BYTES))()
         off = (_C.c_int64 * 2)()
-        _dcheck(self._lib.mi_spmm_dist_export_staging(self._d, h, off), "mi_spmm_dist_export_staging")
-        mine = (bytes(h), [int(off[0]), int(off[1])])
+        code = self._lib.mi_spmm_dist_export_staging(self._d, h, off)
+        mine = (bytes(h), [int(off[0]), int(off[1])]) if code == 0 else None
         if L.world > 1:
             table = [None] * L.world
-            dist.all_gather_object(table, mine, group=self.group)
+            dist.all_gather_object(table, mine, group=self.group)       # every rank takes part, whatever its own export did (see set_peers)
         else:
             table = [mine]
+        _dcheck(code, "mi_spmm_dist_export_staging")
+        if any(t is None for t in table):
+            raise MiSpmmDistError(-5, f"mi_spmm_dist_export_staging on rank(s) {[q for q, t in enumerate(table) if t is None]}")
         handles = (_C.c_char * (2 * IPC_HANDLE_BYTES * L.world))()
         offsets = (_C.c_int64 * (2 * L.world))()
         for q, (hb, ob) in enumerate(table):
