@@ -56,6 +56,10 @@ struct mi_spmm_handle {
     int64_t split_cols;  // 1 (default): columns past the last full 256-column tile get their own launches
     int64_t segment_unroll;  // B-row gathers in flight per lane group in the segment kernel: 8, 16 or 32 (default)
     int64_t tile_cols;       // widest column tile of the rows/segment kernels: 256 (whole wave on a row), 128, 64, 32; 0 = auto
+    int64_t col_strips;      // column strips of the exact segments (plan.hpp): 0 = auto, 1 = off, S >= 2 = that many (if the segments' columns ascend)
+    Chunk *d_strips;         // [n_strips][n_chunks] sub-segments, strip-major (null when n_strips == 1)
+    int32_t n_strips;        // strips in force (1 = none)
+    int32_t seg_unsorted;    // segments whose columns do not ascend (-1: not looked at)
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -120,6 +124,10 @@ static void free_plan(mi_spmm_handle *h)
 {
     drop_graph(h);
     if (h->d_chunks) (void)hipFree(h->d_chunks);
+    if (h->d_strips) (void)hipFree(h->d_strips);
+    h->d_strips = nullptr;
+    h->n_strips = 1;
+    h->seg_unsorted = -1;
     if (h->d_long) (void)hipFree(h->d_long);
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_blk_flag) (void)hipFree(h->d_blk_flag);
@@ -436,6 +444,44 @@ static int side_stream(mi_spmm_handle *h, int i, hipStream_t s, hipStream_t *out
     return MI_SPMM_OK;
 }
 
+namespace { int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb); }
+
+// Column strips of the exact segments (plan.hpp), after either plan builder: the rule's cheap gates first, then one pass over
+// the segments' columns (ascending? how many nonzeros?), then the S sub-segment tables.
+static int plan_col_strips(mi_spmm_handle *h)
+{
+    h->n_strips = 1;
+    h->seg_unsorted = -1;
+    if (h->col_strips == 1 || h->n_chunks <= 0 || h->split_long || h->n_slots > 0 || h->feat <= 0 || h->num_cols < 2) return MI_SPMM_OK;
+    // width of a column tile of the segment kernel at this handle's N (run_part: lane groups of N/4 lanes, capped by the tile rule)
+    const int V = h->feat >= 4 ? 4 : 1;
+    int lpr = 1;
+    while (lpr < (h->feat + V - 1) / V) lpr <<= 1;
+    lpr = lpr < 8 ? 8 : (lpr > 64 ? 64 : lpr);
+    const int cap = resolve_tile_cols(h, h->feat, h->feat) / V;
+    if (V == 4 && lpr > cap) lpr = cap;
+    int tile = lpr * V;
+    if (tile > h->feat) tile = h->feat;
+    if (h->col_strips == 0 && h->local_pct >= 50) return MI_SPMM_OK;      // columns near the row's own position: neighbouring rows share their B rows through L2 already
+    if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
+    if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
+    SegmentSurvey sv;
+    const int rc = survey_segments(h->d_chunks, h->n_chunks, h->d_idx, h->d_col_bad, &sv);
+    if (rc != 0) return rc;
+    h->seg_unsorted = (int32_t)sv.unsorted;
+    if (sv.unsorted) return MI_SPMM_OK;                // a row whose columns do not ascend cannot be cut by column without changing its order
+    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, (int64_t)sv.nnz, h->n_chunks, h->nnz);
+    if (S > h->num_cols) S = h->num_cols;
+    if (S < 2) return MI_SPMM_OK;
+    const size_t bytes = (size_t)S * (size_t)h->n_chunks * sizeof(Chunk);
+    if (hipMalloc((void **)&h->d_strips, bytes) != hipSuccess) { h->d_strips = nullptr; return MI_SPMM_ENOMEM; }
+    const int brc = build_col_strips(h->d_chunks, h->n_chunks, h->d_idx, h->num_cols, (int32_t)S, h->d_strips);
+    if (brc != 0) return brc;
+    h->n_strips = (int32_t)S;
+    h->ws_bytes += bytes;
+    return MI_SPMM_OK;
+}
+
 // preprocess with no host pass over the rows: column check, block detection, classification, scans,
 // segment emission and the length sort all run on the device; one small copy comes back.
 static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_point t0)
@@ -502,6 +548,10 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     {
         const int brc = build_block_items(h);
         if (brc != 0) { free_plan(h); return brc; }
+    }
+    {
+        const int crc = plan_col_strips(h);
+        if (crc != 0) { free_plan(h); return crc; }
     }
     lap(4);
     {
@@ -585,6 +635,9 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->gpu_preprocess = 1;
     h->block_threads = 256;
     h->split_cols = 1;
+    h->col_strips = 0;      // auto (plan.hpp resolve_col_strips)
+    h->n_strips = 1;
+    h->seg_unsorted = -1;
     h->segment_unroll = 32; // whole 32-pair item in flight: 0-13 % faster than 8 on every shape (profiles/r01_segment_unroll.txt)
     *out = h;
     return MI_SPMM_OK;
@@ -657,6 +710,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "split_cols") h->split_cols = v ? 1 : 0;
     else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; }
     else if (k == "segment_unroll") { if (v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
+    else if (k == "col_strips") { if (v < 0 || v > 64) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
@@ -700,6 +754,9 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "block_path") *value = h->block_path;
     else if (k == "n_long_rows") *value = h->n_long;
     else if (k == "n_chunks") *value = h->n_chunks;
+    else if (k == "col_strips") *value = h->col_strips;
+    else if (k == "n_col_strips") *value = h->n_strips;
+    else if (k == "segments_unsorted") *value = h->seg_unsorted;
     else if (k == "workspace_bytes") *value = (int64_t)(h->ws_bytes + h->scratch_a.cap + h->scratch_b.cap);   // plan tables + partial sums + the two preprocess arenas (kept until destroy)
     else if (k == "feat") *value = h->feat;
     else if (k == "num_v") *value = h->num_v;
@@ -937,6 +994,10 @@ static int preprocess_plan(mi_spmm_handle *h)
     {
         const int brc = build_block_items(h);
         if (brc != 0) { free_plan(h); return brc; }
+    }
+    {
+        const int crc = plan_col_strips(h);
+        if (crc != 0) { free_plan(h); return crc; }
     }
     lap(4, tp);
     {
@@ -1205,9 +1266,20 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
             const int fr = side_stream(h, 1, s, &cs);
             if (fr != 0) return fr;
         }
-        if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, cs, (int)h->segment_unroll); }
-        else { if (wide) launch_chunks_lpr<1, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<1, false>(lpr, ca, cgrid, cs); }
-        ++launches;
+        // column strips (plan.hpp): one launch per strip in stream order, each over its own sub-segment table; every strip but the last
+        // leaves the chains in the local C (plain stores, no extra destinations), the last one finishes them like an unstripped launch
+        const int n_strips = h->d_strips ? h->n_strips : 1;
+        for (int st = 0; st < n_strips; ++st) {
+            if (n_strips > 1) {
+                ca.chunks = h->d_strips + (size_t)st * (size_t)h->n_chunks;
+                const bool last = st == n_strips - 1;
+                ca.flags = flags | (last ? (po.n > 0 ? kFlagStripNoSkip : 0) : kFlagStripCarry);
+                if (!last) ca.po.n = 0; else ca.po = po;
+            }
+            if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, cs, (int)h->segment_unroll); }
+            else { if (wide) launch_chunks_lpr<1, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<1, false>(lpr, ca, cgrid, cs); }
+            ++launches;
+        }
     }
 
     const bool remap_blocks = h->xcd_remap != 0;   // list is column-ordered: keep neighbours on one XCD

@@ -75,6 +75,37 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                    const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, int32_t split,
                    Scratch *sa, Scratch *sb, PlanOut *out);
 
+// ---- column strips of the exact segments --------------------------------------------------------------------------
+// A graph of long rows over few columns (protein-, reddit-shaped: hundreds of nonzeros per row, B a few tens of MiB) gathers out of a B that
+// the Infinity Cache holds but an XCD's 4 MiB L2 does not.  Cut every segment at S - 1 column boundaries (columns ascending inside a row:
+// checked) and run strip after strip: a launch then gathers out of K / S rows of B.  survey_segments reads the segments' columns once (are
+// they ascending? how many nonzeros do the segments hold?); build_col_strips writes the S sub-segment tables (strip-major, each in the
+// segment table's order; strip 0 starts the chains, later strips continue them through C: plan_types.hpp kSlotContinue).
+struct SegmentSurvey {
+    uint32_t unsorted;              // segments with a column smaller than its predecessor
+    uint32_t pad;
+    unsigned long long nnz;         // nonzeros in all segments
+};
+int survey_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, void *d_scratch256, SegmentSurvey *out);   // synchronises (one 16-byte copy)
+int build_col_strips(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, int32_t K, int32_t S, Chunk *d_strips);   // asynchronous on the null stream
+// the rule: how many strips for this plan (1 = none)
+inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz, int32_t n_segments, int64_t nnz)
+{
+    // Measured on protein- and reddit-shaped graphs at N = 32 / 128 / 256, strips off / 2 / 4 / 8 / 16 interleaved (profiles/r04_col_strips.txt):
+    // the best strip holds 4 - 8 MiB of B per column tile (one to two XCD L2s; smaller strips pay more launches and shorter sub-segments than
+    // they gain in hits), sub-segments down to ~30 nonzeros still pay, and a strip that cannot get below 16 MiB buys nothing.
+    if (n_segments <= 0 || seg_nnz * 2 < nnz) return 1;                 // the segments are not where the step's bytes are
+    const double strip_target = 6.0 * 1048576.0;
+    const double b_bytes = (double)K * 4.0 * (double)tile_cols;
+    int64_t s = (int64_t)(b_bytes / strip_target + 0.5);
+    const int64_t by_len = seg_nnz / n_segments / 32;                   // sub-segments of >= 32 nonzeros on average
+    if (s > by_len) s = by_len;
+    if (s > 16) s = 16;
+    if (s < 2) return 1;
+    if (b_bytes / (double)s > 16.0 * 1048576.0) return 1;               // B far beyond the caches: strips that large buy nothing
+    return (int32_t)s;
+}
+
 // ---- block path: items assembled on the device ---------------------------------------------------
 // d_gp / d_groups: analyze_group_runs' output for the ng qualifying groups.  Pieces are ordered by (pass, list pieces before
 // run pieces, first column, shareable first, longest first, group) with one stable radix sort; run pieces with the same first

@@ -10,9 +10,11 @@ struct Chunk {              // one segment of one row, handled by one lane group
     int32_t beg;            // first nonzero (index into col_idx/vals)
     int32_t end;            // one past the last
     int32_t slot;           // >= 0: row of the partial-sum workspace it writes (piece of a split row)
-                            //  < 0: the segment is the WHOLE row -> result goes straight to C[row]
+                            //  -1: the segment starts the row's chain (from +0) -> result goes straight to C[row]
+                            //  -2 (kSlotContinue): a column strip's sub-segment that continues the chain from C[row]
     int32_t row;            // CSR row it belongs to
 };
+constexpr int32_t kSlotContinue = -2;
 
 struct LongRow {            // a row longer than the split threshold (a hub)
     int32_t row;

@@ -580,4 +580,73 @@ int build_block_items_gpu(const GroupPieces *d_gp, const int32_t *d_groups, int3
     return MI_SPMM_OK;
 }
 
+// ---- column strips of the exact segments (plan.hpp) ---------------------------------------------------------------------------------
+namespace {
+
+// one wave per segment: are its columns ascending (equal neighbours allowed), and how long is it
+__global__ __launch_bounds__(kBlockThreads) void survey_segments_kernel(const Chunk *__restrict__ chunks, int32_t n, const int32_t *__restrict__ col_idx,
+                                                                       SegmentSurvey *out)
+{
+    const int wave = (int)((blockIdx.x * (unsigned)kBlockThreads + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+    if (wave >= n) return;
+    const Chunk c = chunks[wave];
+    int bad = 0;
+    for (int i = c.beg + lane; i + 1 < c.end; i += 64) bad |= col_idx[i] > col_idx[i + 1];
+    bad = __any(bad);
+    if (lane == 0) {
+        if (bad) atomicAdd(&out->unsorted, 1u);
+        atomicAdd(&out->nnz, (unsigned long long)(c.end - c.beg));
+    }
+}
+
+// one thread per (segment, strip): the first nonzero of the segment whose column is >= the strip's first column, and the same for the next strip
+__global__ __launch_bounds__(kBlockThreads) void build_col_strips_kernel(const Chunk *__restrict__ chunks, int32_t n, const int32_t *__restrict__ col_idx,
+                                                                        int32_t K, int32_t S, Chunk *__restrict__ strips)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (t >= (int64_t)n * S) return;
+    const int s = (int)(t / n), ch = (int)(t % n);
+    const Chunk c = chunks[ch];
+    auto lower_bound = [&](int32_t col) {
+        int lo = c.beg, hi = c.end;
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (col_idx[mid] < col) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    Chunk o;
+    o.beg = s == 0 ? c.beg : lower_bound((int32_t)((int64_t)K * s / S));
+    o.end = s == S - 1 ? c.end : lower_bound((int32_t)((int64_t)K * (s + 1) / S));
+    o.slot = s == 0 ? -1 : kSlotContinue;
+    o.row = c.row;
+    strips[(size_t)s * (size_t)n + (size_t)ch] = o;
+}
+
+}  // namespace
+
+int survey_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, void *d_scratch256, SegmentSurvey *out)
+{
+    *out = SegmentSurvey{};
+    if (n_chunks <= 0) return 0;
+    SegmentSurvey *d = (SegmentSurvey *)d_scratch256;     // 256 bytes of device memory the caller owns
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(SegmentSurvey), 0);
+    if (e != hipSuccess) return (int)e;
+    const int64_t blocks = ((int64_t)n_chunks * 64 + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(survey_segments_kernel, dim3((unsigned)blocks), dim3(kBlockThreads), 0, 0, d_chunks, n_chunks, d_col_idx, d);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(out, d, sizeof(SegmentSurvey), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int build_col_strips(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, int32_t K, int32_t S, Chunk *d_strips)
+{
+    if (n_chunks <= 0 || S < 2) return 0;
+    const int64_t blocks = ((int64_t)n_chunks * S + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(build_col_strips_kernel, dim3((unsigned)blocks), dim3(kBlockThreads), 0, 0, d_chunks, n_chunks, d_col_idx, K, S, d_strips);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace mi

@@ -54,7 +54,7 @@ struct RowsArgs {
     PeerOut po;
 };
 
-enum : int32_t { kFlagXcdRemap = 4, kFlagBlockFallback = 8, kFlagFtz = 16 };   // fallback: the block kernels cannot run on this call (alignment): the rows kernel takes the block groups' rows, whatever their length
+enum : int32_t { kFlagXcdRemap = 4, kFlagBlockFallback = 8, kFlagFtz = 16, kFlagStripCarry = 32, kFlagStripNoSkip = 64 };   // fallback: the block kernels cannot run on this call (alignment): the rows kernel takes the block groups' rows, whatever their length
 
 // "flush_denormals" = 1: the arithmetic of the reference's actual BUILD.  nvcc --use_fast_math (W/CMakeLists.txt:46) implies -ftz=true: every
 // multiply-add of spmm_kernel_ref is fma.rn.ftz.f32 -- subnormal inputs count as sign-preserving zeros, a subnormal result is flushed to a
@@ -257,11 +257,10 @@ item_chain(const Pairs<PV> &cur, int cnt, typename Vec<V>::T acc, const float *_
 template <int V, int LPR, int UNROLL, bool WIDE, bool NT>
 __device__ __forceinline__ typename Vec<V>::T
 segment_chain_v2(const int32_t *__restrict__ col_idx, const float *__restrict__ vals,
-                 const float *__restrict__ B, int64_t ldb, int col, int beg, int end, int lig)
+                 const float *__restrict__ B, int64_t ldb, int col, int beg, int end, int lig, typename Vec<V>::T acc)
 {
     constexpr int PV = (LPR >= 32) ? 1 : (32 / LPR);
     constexpr int CH = LPR * PV;
-    typename Vec<V>::T acc = Vec<V>::zero();
     const uint32_t ldb_bytes = (uint32_t)ldb * 4u, col_bytes = (uint32_t)col * 4u;
     Pairs<PV> cur = fetch_pairs<PV, NT>(col_idx, vals, beg + lig * PV, end);
     for (int k0 = beg; k0 < end; k0 += CH) {
@@ -392,11 +391,20 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
         beg = __builtin_amdgcn_readfirstlane(beg);
         end = __builtin_amdgcn_readfirstlane(end);
     }
-    typename Vec<V>::T acc =
-        segment_chain_v2<V, LPR, UNROLL, WIDE, false>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig);
+    // Column strips: a row's exact segment cut at column boundaries into sub-segments, one launch per strip in stream
+    // order, so that a launch gathers out of K / S rows of B (an L2-sized piece) instead of all K.  A sub-segment of a later strip
+    // (kSlotContinue) CONTINUES the row's fma chain from the value the strip before left in C -- an f32 stored and reloaded keeps its
+    // bits, the columns of a row are ascending (checked in preprocess), so the chain still runs over the nonzeros in stored order.
+    const bool cont = c.slot == kSlotContinue;
+    if (cont && beg == end && !(a.flags & kFlagStripNoSkip)) return;      // nothing of this row in this strip: C already holds the chain so far
+    typename Vec<V>::T acc = Vec<V>::zero();
+    const int64_t coff = (int64_t)c.row * a.ldc + col;
+    if (cont) acc = Vec<V>::load(a.C + coff);
+    acc = segment_chain_v2<V, LPR, UNROLL, WIDE, false>(a.col_idx, a.vals, a.B, a.ldb, col, beg, end, lig, acc);
     if (col_ok) {
         if (c.slot >= 0) Vec<V>::template store<false>(a.partials + (int64_t)c.slot * a.ldp + col, acc);
-        else store_c_all<V, true>(a.C, a.po, (int64_t)c.row * a.ldc + col, acc);
+        else if (a.flags & kFlagStripCarry) Vec<V>::template store<false>(a.C + coff, acc);   // a later strip reads it back: plain store, local C only
+        else store_c_all<V, true>(a.C, a.po, coff, acc);
     }
 }
 

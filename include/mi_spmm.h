@@ -164,6 +164,12 @@ const char *mi_spmm_strerror(int code);
  *   "tile_cols"           widest column tile of the rows / segment kernels: 256 (one row per wavefront), 128, 64, 32;
  *                         0 = auto.  Tiles are swept one after the other, so this sets the B working set of a sweep
  *                         (K x tile_cols x 4 bytes).  Scheduling only: results do not depend on it
+ *   "col_strips"          column strips of the exact segments: every segment is cut at S - 1 column boundaries and the segment kernel runs
+ *                         strip after strip (S launches in stream order), each continuing the rows' fma chains through C, so that a launch
+ *                         gathers out of K / S rows of B -- an L2-sized piece when B is a few tens of MiB (graphs of long rows over few
+ *                         columns: 1.2 - 1.6 x).  0 = auto (hpc_amd/csrc/plan.hpp resolve_col_strips: about 8 MiB of B per strip and column
+ *                         tile, sub-segments of >= 64 nonzeros, at most 16 strips), 1 = off, 2 .. 64 = that many.  Needs ascending columns in
+ *                         every segment (checked by preprocess; otherwise no strips).  Scheduling only: results do not depend on it
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto
  *   "gpu_preprocess"      1 (default): segment table built on the device; 0: reference-style host loop
  *   "kernel"              2: pipelined items (spmm_rows_v2).  1 named the first-generation kernel: MI_SPMM_EUNSUPPORTED
@@ -180,7 +186,8 @@ const char *mi_spmm_strerror(int code);
  *   "n_medium_rows", "n_chunks", "n_partial_slots", "workspace_bytes" (plan tables + partial sums + preprocess arenas),
  *   "n_launches", "lanes_per_row", "preprocess_us", "feat", "num_v", "num_cols", "max_row_nnz",
  *   "n_block_groups", "n_block_pieces", "n_block_items", "n_block_shared_items", "n_block_passes",
- *   "column_locality_pct" (share of sampled nonzeros near their row's own position; behind the "tile_cols" auto rule) */
+ *   "column_locality_pct" (share of sampled nonzeros near their row's own position; behind the "tile_cols" auto rule),
+ *   "n_col_strips" (strips in force, 1 = none), "segments_unsorted" (segments whose columns do not ascend; -1 = not looked at) */
 int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t value);
 int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value);
 

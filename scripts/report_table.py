@@ -101,17 +101,17 @@ def main():
                 del ro
             rows_out[N].append((name, M, nnz, int(deg.max()), t_vend, t_ours, t_vend / t_ours, t_stud, t_stud / t_ours, ok,
                                 ours.get_option("n_hub_rows"), ours.get_option("n_partial_slots"), ours.get_option("long_row_threshold"),
-                                t_graph, same, ours.get_option("n_launches")))
+                                t_graph, same, ours.get_option("n_launches"), ours.get_option("n_col_strips")))
             del d_B, d_C, d_V, ours, vend
         del d_ptr, d_idx, d_val, g
         torch.cuda.empty_cache()
     print("# Reference-style report table on MI355X (dataset-shaped synthetic graphs; see scripts/report_table.py)\n")
     for N in lens:
         print(f"### `kLen = {N}`\n")
-        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | ours with use_graph = 1 (same bits?) | saved by the graph (us) |")
-        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | column strips of the segments | ours with use_graph = 1 (same bits?) | saved by the graph (us) |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
         for r in rows_out[N]:
-            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[13]:.6g} ({'same' if r[14] else 'DIFFERENT'}) | {(r[5] - r[13]) * 1e6:.1f} |")
+            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[16] if r[16] > 1 else '-'} | {r[13]:.6g} ({'same' if r[14] else 'DIFFERENT'}) | {(r[5] - r[13]) * 1e6:.1f} |")
         sp = [r[6] for r in rows_out[N]]
         if sp:
             print(f"\nspeed-up over the vendor library: min {min(sp):.2f}, geometric mean {float(np.exp(np.mean(np.log(sp)))):.2f}, max {max(sp):.2f} "

@@ -1359,8 +1359,10 @@ def test_gpu_and_host_plan_builders_agree(device, oracle):
         for thr, split in ((0, 0), (100, 0), (0, 1), (100, 1)):    # auto and a low explicit threshold; hubs whole or in pieces
             res = {}
             for gpu_pre in (1, 0):
+                # ("col_strips" off: its auto rule looks at the column-locality sample, which only the device builder takes;
+                #  forced strip counts through both builders: test_column_strips_keep_every_bit)
                 C, op = run_spmm(device, ptr, idx, vals, B, options={"gpu_preprocess": gpu_pre, "long_row_threshold": thr,
-                                                                    "long_row_chunk": 64, "split_long_rows": split})
+                                                                    "long_row_chunk": 64, "split_long_rows": split, "col_strips": 1})
                 res[gpu_pre] = (C, {k: op.get_option(k) for k in ("n_chunks", "n_long_rows", "n_hub_rows", "n_medium_rows", "n_partial_slots",
                                                                   "n_block_groups", "max_row_nnz", "long_row_threshold", "n_block_items",
                                                                   "n_block_pieces", "n_block_passes", "n_block_shared_items", "n_launches")})
@@ -1477,3 +1479,146 @@ def test_wide_addressing_variants(device, oracle):
     assert op.get_option("wide_addressing") == 1
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(oracle.spmm_omp(ptr, idx, vals, Bs)))
     del d_B
+
+
+# ---- column strips of the exact segments (plan.hpp resolve_col_strips) ----
+def _strip_case(M, K, lo, hi, seed, hubs=()):
+    ptr, idx = synth.csr_uniform(M, lo, hi, K=K, seed=seed)          # columns ascending and distinct inside a row
+    if hubs:
+        g = np.random.Generator(np.random.Philox(key=[77, seed]))
+        deg = np.diff(ptr).astype(np.int64)
+        rows = g.choice(M, size=len(hubs), replace=False)
+        for r, L in zip(rows, hubs):
+            deg[r] = L
+        new_ptr = np.zeros(M + 1, np.int64)
+        np.cumsum(deg, out=new_ptr[1:])
+        new_idx = np.empty(int(new_ptr[-1]), np.int32)
+        for r in range(M):
+            if deg[r] == ptr[r + 1] - ptr[r]:
+                new_idx[new_ptr[r]:new_ptr[r + 1]] = idx[ptr[r]:ptr[r + 1]]
+            else:
+                new_idx[new_ptr[r]:new_ptr[r + 1]] = np.sort(g.choice(K, int(deg[r]), replace=False)).astype(np.int32)
+        ptr, idx = new_ptr.astype(np.int32), new_idx
+    return ptr, idx
+
+
+@pytest.mark.parametrize("N", [4, 32, 100, 128, 256, 300])
+def test_column_strips_keep_every_bit(device, oracle, N):
+    """"col_strips" = S cuts every exact segment at S - 1 column boundaries and runs strip after strip, each continuing the rows' fma
+    chains through C: scheduling only.  Forced strip counts (also more strips than a short row has nonzeros: empty sub-segments), short,
+    medium and hub rows side by side, pitched B / C, ragged row-range calls, both plan builders: always the oracle's bits."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M, K = 1500, 2300
+    ptr, idx = _strip_case(M, K, 0, 260, seed=31 + N, hubs=(900, 1500, 2299))
+    vals = synth.normal_f32(idx.size, 32)
+    ldb, ldc = N + (0 if N % 8 else 4), N + (3 if N == 100 else 0)
+    Bp = synth.normal_f32(K * ldb, 33).reshape(K, ldb)
+    exp = oracle.spmm_omp(ptr, idx, vals, np.ascontiguousarray(Bp[:, :N]))
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
+    for S, gpu_pre, ranges in ((2, 1, False), (3, 1, True), (5, 0, False), (8, 1, True), (33, 1, False), (1, 1, False), (0, 1, False)):
+        d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+        for k, v in {"col_strips": S, "medium_row_threshold": 24, "long_row_threshold": 512, "gpu_preprocess": gpu_pre}.items():
+            op.set_option(k, v)
+        op.preprocess(d_B, d_C)
+        assert op.get_option("n_long_rows") == 3 and op.get_option("n_medium_rows") > 1000
+        assert op.get_option("n_col_strips") == (S if S >= 2 else 1), (S, op.get_option("n_col_strips"))   # auto (0): far too small a B to strip
+        if S != 1 and S != 0:
+            assert op.get_option("segments_unsorted") == 0
+        for rep in range(2):                           # idempotent: strip 0 starts every chain from +0 again
+            if ranges:
+                for r0, r1 in ((0, 1), (1, 700), (700, 701), (701, M)):
+                    op.run_rows(d_B, ldb, d_C, ldc, r0, r1)
+            else:
+                op.run_ld(d_B, ldb, d_C, ldc)
+        torch.cuda.synchronize()
+        got = d_C.cpu().numpy()
+        assert np.array_equal(bits(got[:, :N]), bits(exp)), (S, gpu_pre, int((bits(got[:, :N]) != bits(exp)).sum()))
+        assert np.isnan(got[:, N:]).all()
+
+
+def test_column_strips_need_ascending_columns_and_survive_special_values(device, oracle):
+    """A row whose columns do not ascend cannot be cut by column without changing its order: one such segment switches the strips off
+    for the plan ("segments_unsorted" says how many).  Equal neighbours (duplicate columns) are fine.  inf, NaN, -0 and subnormals
+    cross strip boundaries unchanged: a strip hands the chain on as the f32 it is."""
+    M, K, N = 600, 900, 64
+    ptr, idx = _strip_case(M, K, 40, 300, seed=5)
+    vals = synth.normal_f32(idx.size, 6)
+    B = synth.normal_f32(K * N, 7).reshape(K, N)
+    opts = {"col_strips": 4, "medium_row_threshold": 16, "long_row_threshold": 4096}
+    # (1) sorted with duplicates
+    idx_dup = idx.copy()
+    for r in range(0, M, 7):
+        b, e = ptr[r], ptr[r + 1]
+        if e - b > 3:
+            idx_dup[b + 1] = idx_dup[b]
+            idx_dup[e - 1] = idx_dup[e - 2]
+    C, op = run_spmm(device, ptr, idx_dup, vals, B, options=opts)
+    assert op.get_option("n_col_strips") == 4 and op.get_option("segments_unsorted") == 0
+    assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx_dup, vals, B)))
+    # (2) one unsorted segment
+    idx_bad = idx.copy()
+    b = ptr[300]
+    idx_bad[b], idx_bad[b + 5] = idx_bad[b + 5], idx_bad[b]
+    C, op = run_spmm(device, ptr, idx_bad, vals, B, options=opts)
+    assert op.get_option("n_col_strips") == 1 and op.get_option("segments_unsorted") == 1
+    assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx_bad, vals, B)))
+    # (3) special values on both sides of the strip boundaries
+    v = vals.copy()
+    Bs = B.copy()
+    g = np.random.Generator(np.random.Philox(key=[9, 9]))
+    v[g.integers(0, v.size, 40)] = np.float32(np.inf)
+    v[g.integers(0, v.size, 40)] = np.float32(-0.0)
+    v[g.integers(0, v.size, 200)] = np.float32(1e-30)
+    Bs[g.integers(0, K, 30), g.integers(0, N, 30)] = np.float32(np.nan)
+    Bs[g.integers(0, K, 200), :] *= np.float32(-1e-12)
+    Bs[g.integers(0, K, 50), :] = np.float32(-1e-30)
+    for ftz in (0, 1):
+        C, op = run_spmm(device, ptr, idx, v, Bs, options=dict(opts, flush_denormals=ftz))
+        assert op.get_option("n_col_strips") == 4
+        ref = oracle.spmm_ftz(ptr, idx, v, Bs) if ftz else oracle.spmm_omp(ptr, idx, v, Bs)
+        assert np.array_equal(bits(C), bits(ref)), ftz
+
+
+def test_column_strips_auto_rule_and_extra_destinations(device, oracle):
+    """The rule picks strips on a graph of long rows over few columns (B = 16 MiB at N = 64: three strips of 5.3 MiB) and leaves C1-like
+    graphs alone; with extra destinations (the multi-GPU peer_store exchange) only the LAST strip stores into them, and it does so for
+    every row -- also rows with no nonzero in the last strip."""
+    import ctypes
+
+    import torch
+    from hpc_amd import CSR, SpMMOpt, _lib
+
+    M = K = 65536
+    N = 64
+    ptr, idx = synth.csr_uniform(M, 150, 350, K=K, seed=12)
+    # a quarter of the rows only use the first half of the columns: nothing of them in the last strip
+    for r in range(0, M, 4):
+        seg = idx[ptr[r]:ptr[r + 1]]
+        idx[ptr[r]:ptr[r + 1]] = np.sort(seg // 2)
+    vals = synth.normal_f32(idx.size, 13)
+    B = synth.normal_f32(K * N, 14).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N)
+    op.preprocess(d_B, d_C)
+    assert op.get_option("n_col_strips") == 3, op.get_option("n_col_strips")
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    # extra destinations
+    extra = [torch.full((M, N), float("nan"), dtype=torch.float32, device=device) for _ in range(2)]
+    arr = (ctypes.c_void_p * 2)(*[ctypes.c_void_p(t.data_ptr()) for t in extra])
+    d_C.fill_(float("nan"))
+    rc = _lib.load().mi_spmm_run_rows_multi(op._h, ctypes.c_void_p(d_B.data_ptr()), N, ctypes.c_void_p(d_C.data_ptr()), N, 0, M, 2, arr, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for t in [d_C] + extra:
+        assert np.array_equal(bits(t.cpu().numpy()), bits(exp))
+    # C1-like: short rows, B far beyond the caches -> no strips, no survey
+    p1, i1 = synth.csr_uniform(20000, 16, 48, seed=3)
+    C1, op1 = run_spmm(device, p1, i1, synth.normal_f32(i1.size, 1), synth.normal_f32(20000 * 32, 2).reshape(20000, 32))
+    assert op1.get_option("n_col_strips") == 1 and op1.get_option("segments_unsorted") == -1
