@@ -1189,8 +1189,8 @@ def test_rmat_and_banded_structures(device, oracle):
 
 def test_fuzz_shapes_pitches_thresholds(device, oracle):
     """80 seeded random cases: ragged shapes, K != M, odd widths, row pitches wider than N, both rows
-    kernels, random medium / hub thresholds, hubs in stored order (default) or split -- always bit-equal to the oracle in the
-    documented order."""
+    kernels, random medium / hub thresholds, hubs in stored order (default) or split, column strips of the segments off / auto / forced -- always
+    bit-equal to the oracle in the documented order."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
@@ -1212,7 +1212,8 @@ def test_fuzz_shapes_pitches_thresholds(device, oracle):
         opts = {"medium_row_threshold": int(g.choice([0, 1, 5, 64, 1000])),
                 "long_row_threshold": int(g.choice([6, 40, 2048])), "long_row_chunk": int(g.choice([3, 16, 256])),
                 "block_path": int(g.choice([0, 1])), "segment_unroll": int(g.choice([8, 16, 32])), "split_long_rows": int(case % 3 == 2),
-                "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3], "segment_overlap": (case // 3) % 2}
+                "hub_slice": (0, 16, 32, 64)[case % 4], "hub_overlap": (1, 2, 0)[case % 3], "segment_overlap": (case // 3) % 2,
+                "col_strips": (0, 2, 1, 3, 7)[case % 5]}      # forced strip counts take effect where the segments' columns ascend and no row is split
         d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, Bp)
         d_C = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=device)
         op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
