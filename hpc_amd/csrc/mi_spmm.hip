@@ -57,7 +57,8 @@ struct mi_spmm_handle {
     int64_t segment_unroll;  // B-row gathers in flight per lane group in the segment kernel: 8, 16 or 32 (default)
     int64_t tile_cols;       // widest column tile of the rows/segment kernels: 256 (whole wave on a row), 128, 64, 32; 0 = auto
     int64_t col_strips;      // column strips of the exact segments (plan.hpp): 0 = auto, 1 = off, S >= 2 = that many (if the segments' columns ascend)
-    Chunk *d_strips;         // [n_strips][n_chunks] sub-segments, strip-major (null when n_strips == 1)
+    Chunk *d_strips;         // [n_strips][n_chunks] sub-segments, strip-major; grow-only buffer (capacity strips_cap sub-segments), kept across preprocess calls
+    size_t strips_cap;
     int32_t n_strips;        // strips in force (1 = none)
     int32_t seg_unsorted;    // segments whose columns do not ascend (-1: not looked at)
     // plan
@@ -124,9 +125,7 @@ static void free_plan(mi_spmm_handle *h)
 {
     drop_graph(h);
     if (h->d_chunks) (void)hipFree(h->d_chunks);
-    if (h->d_strips) (void)hipFree(h->d_strips);
-    h->d_strips = nullptr;
-    h->n_strips = 1;
+    h->n_strips = 1;         // (the strip buffer itself is grow-only: released by destroy)
     h->seg_unsorted = -1;
     if (h->d_long) (void)hipFree(h->d_long);
     if (h->d_partials) (void)hipFree(h->d_partials);
@@ -473,8 +472,14 @@ static int plan_col_strips(mi_spmm_handle *h)
     int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, (int64_t)sv.nnz, h->n_chunks, h->nnz);
     if (S > h->num_cols) S = h->num_cols;
     if (S < 2) return MI_SPMM_OK;
-    const size_t bytes = (size_t)S * (size_t)h->n_chunks * sizeof(Chunk);
-    if (hipMalloc((void **)&h->d_strips, bytes) != hipSuccess) { h->d_strips = nullptr; return MI_SPMM_ENOMEM; }
+    const size_t need = (size_t)S * (size_t)h->n_chunks, bytes = need * sizeof(Chunk);
+    if (h->strips_cap < need) {
+        if (h->d_strips) (void)hipFree(h->d_strips);
+        h->d_strips = nullptr;
+        h->strips_cap = 0;
+        if (hipMalloc((void **)&h->d_strips, bytes) != hipSuccess) { h->d_strips = nullptr; return MI_SPMM_ENOMEM; }
+        h->strips_cap = need;
+    }
     const int brc = build_col_strips(h->d_chunks, h->n_chunks, h->d_idx, h->num_cols, (int32_t)S, h->d_strips);
     if (brc != 0) return brc;
     h->n_strips = (int32_t)S;
@@ -662,6 +667,7 @@ int mi_spmm_destroy(mi_spmm_handle *h)
     scratch_release(&h->scratch_b);
     if (h->d_col_bad) (void)hipFree(h->d_col_bad);
     if (h->d_blk_items) (void)hipFree(h->d_blk_items);
+    if (h->d_strips) (void)hipFree(h->d_strips);
     for (int i = 0; i < 2; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -1268,7 +1274,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         }
         // column strips (plan.hpp): one launch per strip in stream order, each over its own sub-segment table; every strip but the last
         // leaves the chains in the local C (plain stores, no extra destinations), the last one finishes them like an unstripped launch
-        const int n_strips = h->d_strips ? h->n_strips : 1;
+        const int n_strips = (h->d_strips && h->n_strips > 1) ? h->n_strips : 1;
         for (int st = 0; st < n_strips; ++st) {
             if (n_strips > 1) {
                 ca.chunks = h->d_strips + (size_t)st * (size_t)h->n_chunks;
