@@ -148,6 +148,13 @@ def build_inputs(args, world, rank):
     elif name == "DENSEISH":      # reddit/protein/ddi-like: hundreds of nonzeros in every row
         M = M or (1 << 18)
         ptr, idx = synth.csr_uniform(M, 300, 700)
+    elif name == "LONGROWS":      # the `also` entry LONG_ROWS as a configuration of its own (profiles): built on the device, copied back
+        import torch
+
+        M = M or (1 << 17)
+        d_p, d_i = synth.csr_long_rows_device(M, torch.device("cuda", torch.cuda.current_device()))
+        ptr, idx = d_p.cpu().numpy(), d_i.cpu().numpy()
+        del d_p, d_i
     elif name == "BANDED":
         M = M or (1 << 20)
         ptr, idx = synth.csr_banded(M)
@@ -742,7 +749,10 @@ def also_configs(args, dev, c1_tensors, M):
         except Exception:
             traffic_file = {}
 
-    def run_one(tag, d_ptr, d_idx, n, nnz, extra):
+    M_c1 = M
+
+    def run_one(tag, d_ptr, d_idx, n, nnz, extra, M=None):
+        M = M_c1 if M is None else M
         d_val = torch.empty(nnz, dtype=torch.float32, device=dev)
         fill_normal(d_val, synth.SEED_VALS)
         d_B = torch.empty(M * n, dtype=torch.float32, device=dev)
@@ -772,7 +782,7 @@ def also_configs(args, dev, c1_tensors, M):
         model = synth.bytes_model(M, M, n, nnz)
         flops = 2.0 * nnz * n
         tj = traffic_file.get(tag)
-        traffic = tj.get("hbm_bytes_per_launch") if tj and tj.get("N") == n and M == (1 << 20) else None
+        traffic = tj.get("hbm_bytes_per_launch") if tj and tj.get("N") == n and M == tj.get("M", 1 << 20) else None
         src = ({"file": tj.get("source"), "commit": tj.get("commit"), "note": "rocprofv3 --pmc passes at that commit, not this run",
                 **traffic_staleness(tj)} if traffic is not None else None)
         n_blk = op.get_option("n_block_groups")
@@ -794,7 +804,7 @@ def also_configs(args, dev, c1_tensors, M):
         out = {"config": f"{tag}: {extra}, M=K={M}, nnz={nnz}, N={n} fp32", "ms_per_step": round(ms, 4), "steps": n_steps,
                "value": round(flops / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "preprocess_ms": round(pre_ms, 2), "roofline": roof,
                "summation_order": ("exact (stored order on every row)" if not op.get_option("split_long_rows") else "split"),
-               "options": {k: op.get_option(k) for k in ("long_row_threshold", "n_hub_rows", "n_medium_rows", "lanes_per_row", "tile_cols")}}
+               "options": {k: op.get_option(k) for k in ("long_row_threshold", "n_hub_rows", "n_medium_rows", "lanes_per_row", "tile_cols", "n_col_strips")}}
         del op, d_val, d_B, d_C
         torch.cuda.empty_cache()
         return out
@@ -813,6 +823,15 @@ def also_configs(args, dev, c1_tensors, M):
         del d_ptr, d_idx
     except Exception as e:
         res["C4"] = {"error": repr(e)[:200]}
+    try:
+        # long rows over few columns (protein- / reddit-like): the segments run strip by strip out of an L2-sized piece of B
+        Md = max(4096, M // 8)
+        d_ptr, d_idx = synth.csr_long_rows_device(Md, dev)
+        res["LONG_ROWS"] = run_one("LONG_ROWS", d_ptr, d_idx, 128, int(d_idx.numel()),
+                                   "300-700 nonzeros in every row, columns ascending over all K (generated on the device)", M=Md)
+        del d_ptr, d_idx
+    except Exception as e:
+        res["LONG_ROWS"] = {"error": repr(e)[:200]}
     try:
         d_ptr, d_idx, nnz = c1_tensors
         res["C1_N1024"] = run_one("C1_N1024", d_ptr, d_idx, 1024, nnz, "C1's CSR, the one-GPU leg of configs[3]")

@@ -211,6 +211,28 @@ def csr_block_dense_fast_device(M, device, rows_per_block=16, K=None, seed=SEED_
     return ptr.to(torch.int32), col
 
 
+def csr_long_rows_device(M, device, lo=300, hi=700, K=None, seed=SEED_STRUCT):
+    """Long rows over few columns (protein- / reddit- / ddi-like: hundreds of nonzeros in every row), built on the device in well
+    under a second: row lengths ~ Uniform{lo..hi} (host draw), row r's j-th column = floor((j + u) * K / len_r) with u ~ U[0, 1)
+    drawn on the device -- ascending inside a row (equal neighbours are possible and allowed), spread over all K columns.
+    `bench.py`'s `also` entry for the column strips of the segments.  Returns device int32 tensors (row_ptr, col_idx)."""
+    import torch
+
+    K = M if K is None else K
+    deg = torch.from_numpy(_rng(seed, 7).integers(lo, hi + 1, size=M, dtype=np.int64)).to(device)
+    ptr = torch.zeros(M + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=ptr[1:])
+    nnz = int(ptr[-1].item())
+    assert nnz <= np.iinfo(np.int32).max
+    rows = torch.repeat_interleave(torch.arange(M, dtype=torch.int64, device=device), deg)
+    pos = torch.arange(nnz, dtype=torch.int64, device=device) - ptr[:-1][rows]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    u = torch.rand(nnz, generator=gen, device=device, dtype=torch.float64)
+    col = ((pos.to(torch.float64) + u) * (float(K) / deg[rows].to(torch.float64))).floor().clamp_(0, K - 1)
+    return ptr.to(torch.int32), col.to(torch.int32)
+
+
 def csr_rmat(scale, edge_factor=32, a=0.57, b=0.19, c=0.19, seed=SEED_STRUCT):
     """R-MAT / Kronecker graph (Chakrabarti, Zhan, Faloutsos 2004; Graph500 parameters): M = 2^scale rows,
     about edge_factor * M edges before duplicate removal.  Hubs with 10^4..10^5 nonzeros next to empty rows --

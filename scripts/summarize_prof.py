@@ -83,6 +83,8 @@ def main():
         ent["kernel_sources_sha256"] = kernel_sources_sha256()      # bench.py: "traffic_stale" when the tree's differs
         if "--feat" in sys.argv:
             ent["N"] = int(sys.argv[sys.argv.index("--feat") + 1])
+        if "--rows" in sys.argv:                                    # rows of the workload when it is not 2^20 (bench.py matches on it)
+            ent["M"] = int(sys.argv[sys.argv.index("--rows") + 1])
         for k in ("l2_hit_rate", "mfma_busy_frac"):
             if k in step:
                 ent[k] = step[k]

@@ -42,7 +42,7 @@ def test_single_gpu_line():
     assert "l2_fabric" in r["bound_detail"] and "frac_of_measured_copy_6290" in r
     # the other single-GPU BASELINE configurations ride in the same line (timed after the headline's region)
     also = d["also"]
-    assert set(also) == {"C2", "C4", "C1_N1024"}
+    assert set(also) == {"C2", "C4", "C1_N1024", "LONG_ROWS"}
     for k, e in also.items():
         assert "error" not in e, (k, e)
         for key in ("config", "ms_per_step", "value", "roofline", "steps", "summation_order"):
@@ -55,6 +55,7 @@ def test_single_gpu_line():
     assert also["C4"]["roofline"]["bound"] == "mfma" and also["C4"]["roofline"]["block_items"]["n_block_groups"] == 65536 // 16
     assert also["C2"]["roofline"]["bound"] == "hbm" and also["C1_N1024"]["roofline"]["bound"] == "hbm"
     assert "N=1024" in also["C1_N1024"]["config"] and "N=256" in also["C4"]["config"]
+    assert also["LONG_ROWS"]["options"]["n_col_strips"] >= 1 and also["LONG_ROWS"]["options"]["n_medium_rows"] > 0
 
 
 @pytest.mark.parametrize("exchange", ["allgather", "direct", "peer2d", "peer_store"])
