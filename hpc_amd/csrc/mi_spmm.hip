@@ -643,7 +643,8 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->col_strips = 0;      // auto (plan.hpp resolve_col_strips)
     h->n_strips = 1;
     h->seg_unsorted = -1;
-    h->segment_unroll = 32; // whole 32-pair item in flight: 0-13 % faster than 8 on every shape (profiles/r01_segment_unroll.txt)
+    h->segment_unroll = 0;  // auto: 32 (the whole 32-pair item in flight: 0-13 % faster than 8 on every shape, profiles/r01_segment_unroll.txt) -- 16 for
+                            // column-strip launches (gathers served by L2 return sooner, occupancy buys more: -2 .. -13 %, profiles/r04_col_strips.txt)
     *out = h;
     return MI_SPMM_OK;
 }
@@ -715,7 +716,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
     else if (k == "split_cols") h->split_cols = v ? 1 : 0;
     else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; }
-    else if (k == "segment_unroll") { if (v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
+    else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "col_strips") { if (v < 0 || v > 64) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -1282,7 +1283,8 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
                 ca.flags = flags | (last ? (po.n > 0 ? kFlagStripNoSkip : 0) : kFlagStripCarry);
                 if (!last) ca.po.n = 0; else ca.po = po;
             }
-            if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, cs, (int)h->segment_unroll); }
+            const int deep = h->segment_unroll > 0 ? (int)h->segment_unroll : (n_strips > 1 ? 16 : 32);
+            if (vec4) { if (wide) launch_chunks_lpr<4, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<4, false>(lpr, ca, cgrid, cs, deep); }
             else { if (wide) launch_chunks_lpr<1, true>(lpr, ca, cgrid, cs); else launch_chunks_lpr<1, false>(lpr, ca, cgrid, cs); }
             ++launches;
         }

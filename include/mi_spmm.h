@@ -159,7 +159,8 @@ const char *mi_spmm_strerror(int code);
  *                         Same kernels, same arguments: same bits.  Read-only: "graph_ready", "graph_captures", "graph_replays"
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
- *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel (8, 16, 32; default 32)
+ *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel: 8, 16, 32; 0 (default) = auto: 32, and 16 for the
+ *                         launches of column strips (below)
  *   "split_cols"          1 (default): up to 64 columns past the last full 256-column tile get their own launches
  *   "tile_cols"           widest column tile of the rows / segment kernels: 256 (one row per wavefront), 128, 64, 32;
  *                         0 = auto.  Tiles are swept one after the other, so this sets the B working set of a sweep
