@@ -187,7 +187,8 @@ _HUB_GRAPHS = {
 @pytest.mark.parametrize("name", list(_HUB_GRAPHS))
 def test_hub_graphs_default_options_bit_identical_to_reference_kernel(device, oracle, name):
     """Graphs whose longest rows are far beyond the split threshold (R-MAT scale 20: a 64 K-nonzero hub; ddi-, reddit- and
-    am-shaped: 2 K ... 155 K), default options: count_bitdiff(ours, spmm_kernel_ref) == 0 over the whole C."""
+    am-shaped: 2 K ... 155 K), default options (the reddit-shaped graph's segments in column strips): count_bitdiff(ours, spmm_kernel_ref) == 0
+    over the whole C."""
     import torch
     from hpc_amd.spmm import count_bitdiff
 
@@ -208,6 +209,8 @@ def test_hub_graphs_default_options_bit_identical_to_reference_kernel(device, or
     assert thr == auto_hub_threshold(M, N, ptr)
     assert op.get_option("n_hub_rows") == int((deg > thr).sum()) and op.get_option("n_partial_slots") == 0
     assert op.get_option("n_hub_rows") > 0 or name == "ddi"     # ddi-shaped: the auto threshold sits near its longest row
+    if name == "reddit":        # long rows over few columns: its segments run in column strips -- checked here against the reference kernel itself
+        assert op.get_option("n_col_strips") >= 2 and op.get_option("segments_unsorted") == 0
     if not oracle.ref_available():
         pytest.fail("oracle/_ref missing")
     d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
