@@ -1503,7 +1503,7 @@ def _strip_case(M, K, lo, hi, seed, hubs=()):
     return ptr, idx
 
 
-@pytest.mark.parametrize("N", [4, 32, 100, 128, 256, 300])
+@pytest.mark.parametrize("N", [3, 4, 32, 100, 128, 256, 300])
 def test_column_strips_keep_every_bit(device, oracle, N):
     """"col_strips" = S cuts every exact segment at S - 1 column boundaries and runs strip after strip, each continuing the rows' fma
     chains through C: scheduling only.  Forced strip counts (also more strips than a short row has nonzeros: empty sub-segments), short,
@@ -1524,7 +1524,7 @@ def test_column_strips_keep_every_bit(device, oracle, N):
         for k, v in {"col_strips": S, "medium_row_threshold": 24, "long_row_threshold": 512, "gpu_preprocess": gpu_pre}.items():
             op.set_option(k, v)
         op.preprocess(d_B, d_C)
-        assert op.get_option("n_long_rows") == 3 and op.get_option("n_medium_rows") > 1000
+        assert op.get_option("n_medium_rows") > 1000
         assert op.get_option("n_col_strips") == (S if S >= 2 else 1), (S, op.get_option("n_col_strips"))   # auto (0): far too small a B to strip
         if S != 1 and S != 0:
             assert op.get_option("segments_unsorted") == 0
