@@ -465,7 +465,7 @@ static int plan_col_strips(mi_spmm_handle *h)
     if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
     if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
     SegmentSurvey sv;
-    const int rc = survey_segments(h->d_chunks, h->n_chunks, h->d_idx, h->d_col_bad, &sv);
+    const int rc = survey_segments(h->d_chunks, h->n_chunks, h->d_idx, (char *)h->d_col_bad + 64, &sv);   // (the first bytes hold the column-range flag a second plan reads again)
     if (rc != 0) return rc;
     h->seg_unsorted = (int32_t)sv.unsorted;
     if (sv.unsorted) return MI_SPMM_OK;                // a row whose columns do not ascend cannot be cut by column without changing its order
@@ -523,23 +523,46 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         if (e != hipSuccess) { free_plan(h); return (int)e; }
     }
     lap(2);
-    PlanOut po;
-    const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
-    const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
-                                  (int32_t)h->long_chunk, (int32_t)h->split_long, &h->scratch_a, &h->scratch_b, &po);
-    h->d_chunks = po.d_chunks;
-    h->d_long = po.d_long;
-    h->d_blk_groups = po.d_blk_groups;
-    if (rc != 0) { free_plan(h); return rc; }
-    h->n_chunks = po.n_chunks;
-    h->n_long = po.n_long;
-    h->n_slots = po.n_slots;
-    h->n_medium = po.n_medium;
-    h->n_blk_groups = po.n_blk_groups;
-    h->max_row_nnz = po.max_len;
-    h->medium_res = po.mthr;
-    h->long_thr = po.thr;
-    h->local_pct = po.local_pct;
+    // The plan, then the column strips of its segments -- and, where strips are in force and the hub threshold was ours to choose, a second plan WITHOUT
+    // hubs when the longest row's sub-chains would hide inside the strips' launches: as stripped segments those rows gather out of L2 like the rest,
+    // where the hub kernel gathers them out of all of B beside the strip launches (reddit-shaped N = 128 / 256: 5.07 -> 4.46, 8.97 -> 8.15 ms).  The longest
+    // row's chain, at 100 ns per nonzero over all strips, has to fit into half of the stripped step's estimate: at N = 32 the same graph's 20 758-nonzero row
+    // would be the step (1.08 -> 1.70 ms) and protein-shaped N = 32 loses 7 % (0.72 -> 0.78): both keep their hubs.  profiles/r04_col_strips.txt section 8
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        PlanOut po;
+        const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
+        const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
+                                      (int32_t)h->long_chunk, (int32_t)h->split_long, &h->scratch_a, &h->scratch_b, &po);
+        h->d_chunks = po.d_chunks;
+        h->d_long = po.d_long;
+        h->d_blk_groups = po.d_blk_groups;
+        if (rc != 0) { free_plan(h); return rc; }
+        h->n_chunks = po.n_chunks;
+        h->n_long = po.n_long;
+        h->n_slots = po.n_slots;
+        h->n_medium = po.n_medium;
+        h->n_blk_groups = po.n_blk_groups;
+        h->max_row_nnz = po.max_len;
+        h->medium_res = po.mthr;
+        h->long_thr = po.thr;
+        h->local_pct = po.local_pct;
+        {
+            const int crc = plan_col_strips(h);
+            if (crc != 0) { free_plan(h); return crc; }
+        }
+        const double step_s = ((double)h->nnz * (4.0 * h->feat + 8.0) + 4.0 * (double)M * h->feat) / 12e12;     // a stripped step: about twice the gather model's rate
+        const bool fold_hubs = attempt == 0 && h->long_thr_user == 0 && !h->split_long && h->n_strips > 1 && h->n_long > 0 &&
+                               (double)h->max_row_nnz * 100e-9 <= 0.5 * step_s;
+        if (!fold_hubs) break;
+        if (h->d_chunks) (void)hipFree(h->d_chunks);
+        if (h->d_long) (void)hipFree(h->d_long);
+        if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
+        h->d_chunks = nullptr;
+        h->d_long = nullptr;
+        h->d_blk_groups = nullptr;
+        h->ws_bytes = 0;
+        h->long_thr = 1 << 30;          // every row up to any length: one exact segment (stripped)
+    }
     if (h->n_blk_groups == 0 && h->d_blk_flag) { (void)hipFree(h->d_blk_flag); h->d_blk_flag = nullptr; }
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)h->n_medium;
     h->ldp = ((int64_t)h->feat + 3) / 4 * 4;
@@ -547,16 +570,12 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     if (h->n_slots > 0) {
         const size_t pb = (size_t)h->n_slots * (size_t)h->ldp * sizeof(float);
         if (hipMalloc((void **)&h->d_partials, pb) != hipSuccess) { free_plan(h); return MI_SPMM_ENOMEM; }
-        h->ws_bytes = pb;
+        h->ws_bytes += pb;
     }
     h->ws_bytes += (size_t)h->n_chunks * sizeof(Chunk) + (size_t)h->n_long * sizeof(LongRow);
     {
         const int brc = build_block_items(h);
         if (brc != 0) { free_plan(h); return brc; }
-    }
-    {
-        const int crc = plan_col_strips(h);
-        if (crc != 0) { free_plan(h); return crc; }
     }
     lap(4);
     {

@@ -1623,3 +1623,24 @@ def test_column_strips_auto_rule_and_extra_destinations(device, oracle):
     p1, i1 = synth.csr_uniform(20000, 16, 48, seed=3)
     C1, op1 = run_spmm(device, p1, i1, synth.normal_f32(i1.size, 1), synth.normal_f32(20000 * 32, 2).reshape(20000, 32))
     assert op1.get_option("n_col_strips") == 1 and op1.get_option("segments_unsorted") == -1
+
+
+def test_column_strips_fold_hubs_whose_chains_hide_inside_the_strips(device, oracle):
+    """Where strips are in force and the hub threshold is the library's to choose, rows above it become stripped segments too when the longest row's
+    sub-chains hide inside the strips' launches (mi_spmm.hip preprocess_on_gpu: 100 ns per nonzero of the longest row against half of the stripped
+    step's estimate); a row too long for that keeps the hubs, and so does an explicit threshold.  Scheduling only: always the oracle's bits."""
+    M = K = 65536
+    N = 128
+    vals_seed = 21
+    for hubs, thr_opt, folded in (((3000, 3000, 2500), 0, True), ((3000, 3000, 2500), 2048, False), ((3000, 60000), 0, False)):
+        ptr, idx = _strip_case(M, K, 150, 350, seed=17, hubs=hubs)
+        vals = synth.normal_f32(idx.size, vals_seed)
+        B = synth.normal_f32(K * N, 22).reshape(K, N)
+        C, op = run_spmm(device, ptr, idx, vals, B, options={"long_row_threshold": thr_opt})
+        assert op.get_option("n_col_strips") >= 2 and op.get_option("segments_unsorted") == 0
+        if folded:
+            assert op.get_option("n_hub_rows") == 0 and op.get_option("long_row_threshold") == 1 << 30
+        else:
+            assert op.get_option("n_hub_rows") == len(hubs) if thr_opt else op.get_option("n_hub_rows") >= 1
+            assert op.get_option("long_row_threshold") < 1 << 30
+        assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (hubs, thr_opt)
