@@ -285,10 +285,14 @@ def main():
     nnz = int(idx.size)
     t_gen = time.time() - t_gen
     d_ptr, d_idx, d_val, d_B = (torch.from_numpy(a).to(dev) for a in (ptr, idx, vals, B_loc))
+    d_Cfull = None
     if multi:      # peers map this buffer (peer2d / peer_store): allocated at a size HIP IPC can open (C1 on 4 GPUs: 2 GiB -> 4 GiB)
-        from hpc_amd.dist import alloc_c_full
-        d_Cfull = alloc_c_full(M, n_total, dev, fill=float("nan"))
-    else:
+        try:
+            from hpc_amd.dist import alloc_c_full
+            d_Cfull = alloc_c_full(M, n_total, dev, fill=float("nan"))
+        except Exception as e:      # no libmi_spmm_dist.so: the Python schedule below still runs (it maps nothing)
+            print(f"[bench] rank {rank}: exportable C_full unavailable ({e!r}); plain allocation", file=sys.stderr, flush=True)
+    if d_Cfull is None:
         d_Cfull = torch.full((M, n_total), float("nan"), dtype=torch.float32, device=dev)
 
     op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), n_loc)
