@@ -1644,3 +1644,46 @@ def test_column_strips_fold_hubs_whose_chains_hide_inside_the_strips(device, ora
             assert op.get_option("n_hub_rows") == len(hubs) if thr_opt else op.get_option("n_hub_rows") >= 1
             assert op.get_option("long_row_threshold") < 1 << 30
         assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B))), (hubs, thr_opt)
+
+
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_column_strips_inside_a_captured_graph(device, oracle, overlap):
+    """The strip launches are ordinary stream-ordered launches: captured into the handle's HIP graph ("use_graph") and into a caller's own
+    capture they replay to the same bits, with the segment kernel on the caller's stream or on its side stream."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M, K, N = 3000, 4000, 64
+    ptr, idx = _strip_case(M, K, 60, 300, seed=41, hubs=(1500, 3999))
+    vals = synth.normal_f32(idx.size, 42)
+    B = synth.normal_f32(K * N, 43).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((M, N), float("nan"), device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
+    for k, v in {"col_strips": 4, "long_row_threshold": 1024, "hub_overlap": overlap, "segment_overlap": 1 if overlap == 2 else 0, "use_graph": 1}.items():
+        op.set_option(k, v)
+    op.preprocess(d_B, d_C)
+    assert op.get_option("n_col_strips") == 4 and op.get_option("graph_ready") == 1 and op.get_option("n_hub_rows") == 2
+    for rep in range(3):
+        d_C.fill_(float("nan"))
+        op.run(d_B, d_C)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    assert op.get_option("graph_replays") == 3 and op.get_option("n_launches") == 5        # hub kernel + 4 strips (no row is short enough for the rows kernel)
+    # a caller's own capture of the plain launches
+    op.set_option("use_graph", 0)
+    op.preprocess(d_B, d_C)
+    s = torch.cuda.Stream(device=device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        op.run(d_B, d_C)                      # warm-up outside the capture
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            op.run(d_B, d_C)
+    for rep in range(2):
+        d_C.fill_(float("nan"))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
