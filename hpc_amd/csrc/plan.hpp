@@ -91,16 +91,16 @@ int build_col_strips(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_c
 // the rule: how many strips for this plan (1 = none)
 inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz, int32_t n_segments, int64_t nnz)
 {
-    // Measured on protein- and reddit-shaped graphs at N = 32 / 128 / 256, strips off / 2 / 4 / 8 / 16 interleaved (profiles/r04_col_strips.txt):
-    // the best strip holds 4 - 8 MiB of B per column tile (one to two XCD L2s; smaller strips pay more launches and shorter sub-segments than
-    // they gain in hits), sub-segments down to ~30 nonzeros still pay, and a strip that cannot get below 16 MiB buys nothing.
+    // Measured on protein- and reddit-shaped graphs at N = 32 / 128 / 256, strip counts interleaved in one process (profiles/r04_col_strips.txt, sections 2
+    // and 9): the best strip holds 4 - 6 MiB of B per column tile (one to one and a half XCD L2s; smaller strips pay more launches and shorter sub-segments
+    // than they gain in hits), sub-segments down to ~20 nonzeros still pay with 16 gathers in flight, and a strip that cannot get below 16 MiB buys nothing.
     if (n_segments <= 0 || seg_nnz * 2 < nnz) return 1;                 // the segments are not where the step's bytes are
-    const double strip_target = 6.0 * 1048576.0;
+    const double strip_target = 5.0 * 1048576.0;
     const double b_bytes = (double)K * 4.0 * (double)tile_cols;
     int64_t s = (int64_t)(b_bytes / strip_target + 0.5);
-    const int64_t by_len = seg_nnz / n_segments / 32;                   // sub-segments of >= 32 nonzeros on average
+    const int64_t by_len = seg_nnz / n_segments / 20;                   // sub-segments of >= 20 nonzeros on average
     if (s > by_len) s = by_len;
-    if (s > 16) s = 16;
+    if (s > 32) s = 32;
     if (s < 2) return 1;
     if (b_bytes / (double)s > 16.0 * 1048576.0) return 1;               // B far beyond the caches: strips that large buy nothing
     return (int32_t)s;

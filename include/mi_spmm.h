@@ -168,8 +168,8 @@ const char *mi_spmm_strerror(int code);
  *   "col_strips"          column strips of the exact segments: every segment is cut at S - 1 column boundaries and the segment kernel runs
  *                         strip after strip (S launches in stream order), each continuing the rows' fma chains through C, so that a launch
  *                         gathers out of K / S rows of B -- an L2-sized piece when B is a few tens of MiB (graphs of long rows over few
- *                         columns: 1.2 - 1.6 x).  0 = auto (hpc_amd/csrc/plan.hpp resolve_col_strips: about 8 MiB of B per strip and column
- *                         tile, sub-segments of >= 64 nonzeros, at most 16 strips), 1 = off, 2 .. 64 = that many.  Needs ascending columns in
+ *                         columns: 1.2 - 1.6 x).  0 = auto (hpc_amd/csrc/plan.hpp resolve_col_strips: about 5 MiB of B per strip and column
+ *                         tile, sub-segments of >= 20 nonzeros, at most 32 strips), 1 = off, 2 .. 64 = that many.  Needs ascending columns in
  *                         every segment (checked by preprocess; otherwise no strips).  Scheduling only: results do not depend on it
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto
  *   "gpu_preprocess"      1 (default): segment table built on the device; 0: reference-style host loop
