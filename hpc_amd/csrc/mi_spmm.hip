@@ -61,6 +61,8 @@ struct mi_spmm_handle {
     size_t strips_cap;
     int32_t n_strips;        // strips in force (1 = none)
     int32_t seg_unsorted;    // segments whose columns do not ascend (-1: not looked at)
+    int64_t seg_nnz;         // nonzeros in the whole segments (either plan builder): the strip rule's input, known before any column is read
+    int64_t strips_builder;  // 0 (default): strip_segments, one pass; 1: the round-4 pair survey_segments + build_col_strips (cross-check)
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -98,6 +100,8 @@ struct mi_spmm_handle {
     // spmm_cusparse.cu:11-15), re-captured by a run() call with another tuple.
     int64_t use_graph;
     hipStream_t gstream;
+    hipStream_t glaunch;        // round 5 experiment: the stream the replay is launched on (tested to run beside the null stream), bracketed by events
+    hipEvent_t ev_gin, ev_gout;
     hipGraphExec_t gexec;
     struct GraphKey { const float *vin; float *vout; int64_t ldb, ldc; int32_t r0, r1, n_extra; float *extra[kMaxPeerOut]; } gkey;
     std::vector<int32_t> *hub_rows_sorted;   // host copy of the hub rows, ascending (null: unknown -> every call launches the hub kernel)
@@ -127,6 +131,7 @@ static void free_plan(mi_spmm_handle *h)
     if (h->d_chunks) (void)hipFree(h->d_chunks);
     h->n_strips = 1;         // (the strip buffer itself is grow-only: released by destroy)
     h->seg_unsorted = -1;
+    h->seg_nnz = 0;
     if (h->d_long) (void)hipFree(h->d_long);
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_blk_flag) (void)hipFree(h->d_blk_flag);
@@ -464,13 +469,18 @@ static int plan_col_strips(mi_spmm_handle *h)
     if (h->col_strips == 0 && h->local_pct >= 50) return MI_SPMM_OK;      // columns near the row's own position: neighbouring rows share their B rows through L2 already
     if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
     if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
+    void *d_sv = (char *)h->d_col_bad + 64;            // (the first bytes hold the column-range flag a second plan reads again)
     SegmentSurvey sv;
-    const int rc = survey_segments(h->d_chunks, h->n_chunks, h->d_idx, (char *)h->d_col_bad + 64, &sv);   // (the first bytes hold the column-range flag a second plan reads again)
-    if (rc != 0) return rc;
-    h->seg_unsorted = (int32_t)sv.unsorted;
-    if (sv.unsorted) return MI_SPMM_OK;                // a row whose columns do not ascend cannot be cut by column without changing its order
-    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, (int64_t)sv.nnz, h->n_chunks, h->nnz);
+    if (h->strips_builder == 1) {                      // round 4: survey first (its nonzero count feeds the rule), tables afterwards
+        const int rc = survey_segments(h->d_chunks, h->n_chunks, h->d_idx, d_sv, &sv);
+        if (rc != 0) return rc;
+        h->seg_unsorted = (int32_t)sv.unsorted;
+        if (sv.unsorted) return MI_SPMM_OK;            // a row whose columns do not ascend cannot be cut by column without changing its order
+        if ((int64_t)sv.nnz != h->seg_nnz) return MI_SPMM_ESTATE;      // the plan builders' count and the survey's are the same number
+    }
+    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz);
     if (S > h->num_cols) S = h->num_cols;
+    if (S > kMaxColStrips) S = kMaxColStrips;
     if (S < 2) return MI_SPMM_OK;
     const size_t need = (size_t)S * (size_t)h->n_chunks, bytes = need * sizeof(Chunk);
     if (h->strips_cap < need) {
@@ -480,8 +490,15 @@ static int plan_col_strips(mi_spmm_handle *h)
         if (hipMalloc((void **)&h->d_strips, bytes) != hipSuccess) { h->d_strips = nullptr; return MI_SPMM_ENOMEM; }
         h->strips_cap = need;
     }
-    const int brc = build_col_strips(h->d_chunks, h->n_chunks, h->d_idx, h->num_cols, (int32_t)S, h->d_strips);
-    if (brc != 0) return brc;
+    if (h->strips_builder == 1) {
+        const int brc = build_col_strips(h->d_chunks, h->n_chunks, h->d_idx, h->num_cols, (int32_t)S, h->d_strips);
+        if (brc != 0) return brc;
+    } else {                                           // one pass: ascending? and the tables, which an unsorted segment leaves unusable
+        const int brc = strip_segments(h->d_chunks, h->n_chunks, h->d_idx, h->num_cols, (int32_t)S, h->d_strips, d_sv, &sv);
+        if (brc != 0) return brc;
+        h->seg_unsorted = (int32_t)sv.unsorted;
+        if (sv.unsorted) return MI_SPMM_OK;
+    }
     h->n_strips = (int32_t)S;
     h->ws_bytes += bytes;
     return MI_SPMM_OK;
@@ -528,7 +545,10 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     // where the hub kernel gathers them out of all of B beside the strip launches (reddit-shaped N = 128 / 256: 5.07 -> 4.46, 8.97 -> 8.15 ms).  The longest
     // row's chain, at 100 ns per nonzero over all strips, has to fit into half of the stripped step's estimate: at N = 32 the same graph's 20 758-nonzero row
     // would be the step (1.08 -> 1.70 ms) and protein-shaped N = 32 loses 7 % (0.72 -> 0.78): both keep their hubs.  profiles/r04_col_strips.txt section 8
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // (attempt 2, ADVICE r4: the folded plan surveys the former hub rows for the first time; if one of them has non-ascending columns, or the rule on
+    //  the new survey says no strips, the fold has nothing to stand on -- a 10^4-nonzero row would run as ONE unstripped segment chain -- and the plan
+    //  with hubs is built again, this time to be kept)
+    for (int attempt = 0; attempt < 3; ++attempt) {
         PlanOut po;
         const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
         const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
@@ -546,6 +566,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         h->medium_res = po.mthr;
         h->long_thr = po.thr;
         h->local_pct = po.local_pct;
+        h->seg_nnz = po.seg_nnz;
         {
             const int crc = plan_col_strips(h);
             if (crc != 0) { free_plan(h); return crc; }
@@ -553,7 +574,8 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         const double step_s = ((double)h->nnz * (4.0 * h->feat + 8.0) + 4.0 * (double)M * h->feat) / 12e12;     // a stripped step: about twice the gather model's rate
         const bool fold_hubs = attempt == 0 && h->long_thr_user == 0 && !h->split_long && h->n_strips > 1 && h->n_long > 0 &&
                                (double)h->max_row_nnz * 100e-9 <= 0.5 * step_s;
-        if (!fold_hubs) break;
+        const bool unfold = attempt == 1 && h->n_strips <= 1;      // the fold lost its strips: back to the plan with hubs
+        if (!fold_hubs && !unfold) break;
         if (h->d_chunks) (void)hipFree(h->d_chunks);
         if (h->d_long) (void)hipFree(h->d_long);
         if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
@@ -561,7 +583,8 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         h->d_long = nullptr;
         h->d_blk_groups = nullptr;
         h->ws_bytes = 0;
-        h->long_thr = 1 << 30;          // every row up to any length: one exact segment (stripped)
+        if (fold_hubs) h->long_thr = 1 << 30;          // every row up to any length: one exact segment (stripped)
+        else h->long_thr = 0;                           // auto threshold again: the first attempt's plan, kept this time
     }
     if (h->n_blk_groups == 0 && h->d_blk_flag) { (void)hipFree(h->d_blk_flag); h->d_blk_flag = nullptr; }
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)h->n_medium;
@@ -583,6 +606,9 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         if (src == 0) src = note_hub_rows(h);
         if (src != 0) { free_plan(h); return src; }
     }
+    // mi_spmm.h: preprocess synchronises.  Everything above ran on the null stream and most of it was waited for by the copies back, but the last
+    // launches (build_col_strips, the block items' device copy) were not: a run() on a non-blocking stream is not ordered behind the null stream.
+    HIP_TRY(hipStreamSynchronize(0));
     h->prepared = true;
     h->preprocess_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return MI_SPMM_OK;
@@ -694,6 +720,9 @@ int mi_spmm_destroy(mi_spmm_handle *h)
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->glaunch) (void)hipStreamDestroy(h->glaunch);
+    if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
+    if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
     h->magic = 0;
     delete h;
     return MI_SPMM_OK;
@@ -704,7 +733,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     if (!good(h) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
     drop_graph(h);     // any option may change the launch set; the next preprocess or run captures it again
-    if (k == "use_graph") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->use_graph = v; }
+    if (k == "use_graph") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->use_graph = v; }
     else if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
@@ -736,7 +765,8 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "split_cols") h->split_cols = v ? 1 : 0;
     else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; }
     else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
-    else if (k == "col_strips") { if (v < 0 || v > 64) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
+    else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
+    else if (k == "col_strips_builder") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->strips_builder = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
     else if (k == "nt_stream") h->nt_stream = v ? 1 : 0;
@@ -783,6 +813,19 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "col_strips") *value = h->col_strips;
     else if (k == "n_col_strips") *value = h->n_strips;
     else if (k == "segments_unsorted") *value = h->seg_unsorted;
+    else if (k == "col_strips_builder") *value = h->strips_builder;
+    else if (k == "segment_nnz") *value = h->seg_nnz;
+    else if (k == "col_strips_table_hash") {           // FNV-1a over the strip tables (copied back: a test's question, not a step's)
+        *value = 0;
+        if (h->prepared && h->d_strips && h->n_strips > 1) {
+            std::vector<Chunk> t((size_t)h->n_strips * (size_t)h->n_chunks);
+            HIP_TRY(hipMemcpy(t.data(), h->d_strips, t.size() * sizeof(Chunk), hipMemcpyDeviceToHost));
+            uint64_t f = 1469598103934665603ull;
+            const unsigned char *b = reinterpret_cast<const unsigned char *>(t.data());
+            for (size_t i = 0; i < t.size() * sizeof(Chunk); ++i) { f ^= b[i]; f *= 1099511628211ull; }
+            *value = (int64_t)(f >> 1);
+        }
+    }
     else if (k == "workspace_bytes") *value = (int64_t)(h->ws_bytes + h->scratch_a.cap + h->scratch_b.cap);   // plan tables + partial sums + the two preprocess arenas (kept until destroy)
     else if (k == "feat") *value = h->feat;
     else if (k == "num_v") *value = h->num_v;
@@ -995,6 +1038,8 @@ static int preprocess_plan(mi_spmm_handle *h)
     }
     h->n_chunks = (int32_t)chunks.size();
     h->n_long = (int32_t)longs.size();
+    h->seg_nnz = 0;
+    for (const Chunk &c : chunks) if (c.slot < 0) h->seg_nnz += c.end - c.beg;
     h->n_medium = n_medium;
     h->n_slots = n_slots;
     h->n_rows_for_rows_kernel = (int64_t)M - 16 * (int64_t)h->n_blk_groups - (int64_t)h->n_long - (int64_t)n_medium;
@@ -1031,6 +1076,7 @@ static int preprocess_plan(mi_spmm_handle *h)
         if (src == 0) src = note_hub_rows(h);
         if (src != 0) { free_plan(h); return src; }
     }
+    HIP_TRY(hipStreamSynchronize(0));      // (as in preprocess_on_gpu: build_col_strips is asynchronous)
     h->prepared = true;
     h->preprocess_us =
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -1421,6 +1467,11 @@ static int capture_launch_set(mi_spmm_handle *h, const mi_spmm_handle::GraphKey 
 {
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     if (!h->gstream && hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess) { h->gfailed = true; return MI_SPMM_ENOMEM; }
+    if (h->use_graph == 2 && !h->glaunch) {
+        int ov = 0;
+        if (concurrent_stream(&h->glaunch, 0, &ov) != MI_SPMM_OK || hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming) != hipSuccess) { h->gfailed = true; return MI_SPMM_ENOMEM; }
+    }
     hipError_t e = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) { (void)hipGetLastError(); h->gfailed = true; return (int)e; }
     const int rc = launch_set(h, key.vin, key.ldb, key.vout, key.ldc, key.r0, key.r1, po, h->gstream);
@@ -1479,6 +1530,14 @@ int mi_spmm_run_rows_multi(mi_spmm_handle *h, const float *d_vin, int64_t ldb, f
                 if (crc != MI_SPMM_OK && !h->gfailed) return crc;      // an argument error of the launch set itself
             }
             if (h->gexec) {
+                if (h->use_graph == 2 && h->glaunch) {
+                    // the replay on a handle-owned stream whose queue was tested to run beside the null stream's, ordered into the caller's stream by two events
+                    HIP_TRY(hipEventRecord(h->ev_gin, s));
+                    HIP_TRY(hipStreamWaitEvent(h->glaunch, h->ev_gin, 0));
+                    HIP_TRY(hipGraphLaunch(h->gexec, h->glaunch));
+                    HIP_TRY(hipEventRecord(h->ev_gout, h->glaunch));
+                    HIP_TRY(hipStreamWaitEvent(s, h->ev_gout, 0));
+                } else
                 HIP_TRY(hipGraphLaunch(h->gexec, s));
                 ++h->graph_replays;
                 h->last_launches = h->glaunches;

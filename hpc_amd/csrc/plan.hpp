@@ -54,6 +54,7 @@ struct PlanOut {
     int32_t mthr = 0;               // resolved medium threshold (the rows kernel skips rows above it)
     int32_t thr = 0;                // resolved hub threshold (the caller's value, or the auto rule above)
     int32_t local_pct = 0;          // sampled nonzeros within a window of their row's own position, percent (column-tile rule)
+    int64_t seg_nnz = 0;            // nonzeros in the whole (exact) segments: lets the column-strip rule pick S before any column is read
 };
 
 // Returns 0, a negative MI_SPMM_E* code (malformed CSR, out of memory) or a positive hipError_t.
@@ -86,6 +87,12 @@ struct SegmentSurvey {
     uint32_t pad;
     unsigned long long nnz;         // nonzeros in all segments
 };
+constexpr int kMaxColStrips = 64;   // "col_strips" accepts 2 .. 64; the auto rule stops at 32
+// Round 5, the default builder: survey and tables in one pass over the segments' columns (S chosen beforehand from PlanOut::seg_nnz).  out->unsorted > 0:
+// the tables are incomplete, drop them.  Synchronises (one 16-byte copy).  The two functions below are the round-4 builder, kept as the cross-check
+// ("col_strips_builder" = 1; test_strip_builders_agree).
+int strip_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, int32_t K, int32_t S, Chunk *d_strips, void *d_scratch256,
+                   SegmentSurvey *out);
 int survey_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, void *d_scratch256, SegmentSurvey *out);   // synchronises (one 16-byte copy)
 int build_col_strips(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, int32_t K, int32_t S, Chunk *d_strips);   // asynchronous on the null stream
 // the rule: how many strips for this plan (1 = none)

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -26,6 +28,7 @@ struct PlanStats {
     int32_t thr;       // resolved hub threshold (the caller's value or resolve_hub_threshold)
     int32_t pad;
     LenHist hist;      // rows above 256 .. 8192 nonzeros and what they hold (the auto hub threshold reads it)
+    unsigned long long seg_nnz;   // nonzeros of the rows that became whole (exact) segments: the column-strip rule reads it
 };
 
 __global__ void init_plan_stats(PlanStats *stats)
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
         seg_cnt[r] = segs;
         slot_cnt[r] = slots;
         long_cnt[r] = lng;
+        if (segs == 0 || slots != 0) len = 0;                  // (below: only whole segments count)
         if (r == 0) { stats->ptr0 = beg; stats->mthr = mthr; stats->thr = thr; if (beg < 0) bad |= 2; }
         if (r == M - 1) stats->ptrM = end;
     } else if (r == M) {   // trailing zero so the exclusive scans leave the totals at index M
@@ -137,6 +141,10 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
         long_cnt[r] = 0;
     }
     if (bad) atomicOr(&stats->bad, bad);   // malformed input only
+    // nonzeros in whole segments, one atomic per wave that has any (r >= M: len = 0)
+    unsigned long long part = (r < M) ? (unsigned long long)len : 0ull;
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((threadIdx.x & 63) == 0 && part) atomicAdd(&stats->seg_nnz, part);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void emit_segments(const int32_t *__restrict__ row_ptr, int32_t M,
@@ -315,6 +323,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     out->n_slots = host.n_slots;
     out->n_long = host.n_long;
     out->n_medium = host.n_chunks - host.n_slots;
+    out->seg_nnz = (int64_t)host.st.seg_nnz;
     if (d_blk_flag && host.st.n_groups_selected > 0) {
         out->n_blk_groups = host.st.n_groups_selected;
         // the qualifying groups in row order; build_block_items (mi_spmm.hip) cuts them into pieces and orders those
@@ -623,7 +632,82 @@ __global__ __launch_bounds__(kBlockThreads) void build_col_strips_kernel(const C
     strips[(size_t)s * (size_t)n + (size_t)ch] = o;
 }
 
+// ---- round 5: survey and tables in ONE pass over the segments' columns -------------------------------------------------------------
+// The two kernels above read every segment's columns twice -- once lane-strided with one same-address atomic pair per segment (132 534 segments:
+// 1.6 ms, the atomics), once through S binary searches per segment -- and cost more than a step of the graphs they serve.
+// Here a wave strides a segment's columns once, coalesced; a lane compares its column with its left neighbour's (ascending?) and, where the two lie in
+// different strips, that position is where the strips in between begin -- exactly lower_bound(first column of the strip).  S comes from the plan's own
+// statistics (PlanStats::seg_nnz), so nothing has to come back from the device before the tables are written; one counter does afterwards.
+// Grid-stride over the segments (longest first in the table, so neighbours in a workgroup carry similar lengths): one atomic per WAVE, and only if it
+// met an unsorted segment.  The tables of a plan with an unsorted segment are incomplete and never used (plan_col_strips drops them).
+__global__ __launch_bounds__(kBlockThreads) void strip_segments_kernel(const Chunk *__restrict__ chunks, int32_t n, const int32_t *__restrict__ col_idx,
+                                                                      int32_t K, int32_t S, Chunk *__restrict__ strips, SegmentSurvey *out)
+{
+    __shared__ int32_t bound[kMaxColStrips + 2];      // bound[s]: first column of strip s; bound[S] = K
+    for (int t = (int)threadIdx.x; t <= S; t += kBlockThreads) bound[t] = (int32_t)((int64_t)K * t / S);
+    __syncthreads();
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = (int)(blockIdx.x * (unsigned)(kBlockThreads / 64) + (threadIdx.x >> 6)), n_waves = (int)(gridDim.x * (unsigned)(kBlockThreads / 64));
+    const float scale = (float)S / (float)K;
+    auto strip_of = [&](int32_t col) {                // the strip that holds column col (0 <= col < K); the float guess is off by one at most
+        int s = (int)((float)col * scale);
+        s = s < 0 ? 0 : (s > S - 1 ? S - 1 : s);
+        while (s + 1 < S && bound[s + 1] <= col) ++s;
+        while (s > 0 && bound[s] > col) --s;
+        return s;
+    };
+    unsigned bad_segments = 0;
+    for (int ch = wave; ch < n; ch += n_waves) {
+        const Chunk c = chunks[ch];
+        if (lane < S) {                                // what does not depend on the columns
+            Chunk *o = strips + (size_t)lane * (size_t)n + (size_t)ch;
+            o->slot = lane == 0 ? -1 : kSlotContinue;
+            o->row = c.row;
+            if (lane == 0) o->beg = c.beg;
+        }
+        int bad = 0;
+        int32_t carry = -1;                            // column in front of this batch ("-1" lies in strip 0: strip 0 begins at c.beg)
+        // positions c.beg .. c.end INCLUSIVE: the virtual element at c.end sits past the last strip and closes every strip still open
+        for (int base = c.beg; base <= c.end; base += 64) {
+            const int i = base + lane;
+            const int32_t col = i < c.end ? col_idx[i] : INT32_MAX;
+            int32_t prev = __shfl_up(col, 1, 64);
+            if (lane == 0) prev = carry;
+            carry = __shfl(col, 63, 64);
+            if (i <= c.end) {
+                bad |= col < prev;
+                const int sp = prev < 0 ? 0 : strip_of(prev);
+                const int sc = i < c.end ? strip_of(col) : S;
+                for (int s = sp + 1; s <= sc; ++s) {   // strips sp+1 .. sc begin here, strips sp .. sc-1 end here (no trip at all for most lanes)
+                    if (s < S) strips[(size_t)s * (size_t)n + (size_t)ch].beg = i;
+                    strips[(size_t)(s - 1) * (size_t)n + (size_t)ch].end = i;
+                }
+            }
+        }
+        if (__any(bad)) ++bad_segments;
+    }
+    if (lane == 0 && bad_segments) atomicAdd(&out->unsorted, bad_segments);
+}
+
 }  // namespace
+
+int strip_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, int32_t K, int32_t S, Chunk *d_strips, void *d_scratch256,
+                   SegmentSurvey *out)
+{
+    *out = SegmentSurvey{};
+    if (n_chunks <= 0 || S < 2 || S > kMaxColStrips) return 0;
+    SegmentSurvey *d = (SegmentSurvey *)d_scratch256;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(SegmentSurvey), 0);
+    if (e != hipSuccess) return (int)e;
+    // enough waves to fill the chip eight deep, never more than there are segments
+    int64_t blocks = ((int64_t)n_chunks + kBlockThreads / 64 - 1) / (kBlockThreads / 64);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(strip_segments_kernel, dim3((unsigned)blocks), dim3(kBlockThreads), 0, 0, d_chunks, n_chunks, d_col_idx, K, S, d_strips, d);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(out, d, sizeof(SegmentSurvey), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 int survey_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, void *d_scratch256, SegmentSurvey *out)
 {

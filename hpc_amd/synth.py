@@ -272,6 +272,161 @@ def csr_banded(M, deg_lo=16, deg_hi=48, width=2048, seed=SEED_STRUCT):
     return ptr.astype(np.int32), cols
 
 
+# ---- structured graphs (round 5): nothing below draws its columns uniformly at random ---------------------------------
+# The reference's 13 course graphs are community-structured, symmetric adjacency matrices with correlated degrees: a hub ROW is also a hub COLUMN
+# (its B row is gathered by thousands of rows), neighbours share neighbours, and a BFS / RCM / partitioner ordering puts a community's vertices next to
+# each other.  The dataset-shaped stand-ins above have none of that.  These generators do, in well under a second on the device (torch), so that the
+# auto rules (tile width, column strips, hub threshold, side streams, hub slices) meet such inputs: scripts/regret.py.
+
+
+def _powerlaw_weights(M, mean_deg, max_deg, alpha, seed, stream):
+    """Expected degrees with csr_powerlaw's profile (host, M numbers): min(max_deg, d_min * u^(-1/alpha)), mean = mean_deg; the longest = max_deg."""
+    u = _rng(seed, stream).random(M)
+    w = u ** (-1.0 / alpha)
+    lo, hi = 1e-3, float(mean_deg)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if np.minimum(max_deg, mid * w).mean() < mean_deg:
+            lo = mid
+        else:
+            hi = mid
+    w = np.minimum(float(max_deg), hi * w)
+    if M > 0:
+        w[int(np.argmax(w))] = float(min(max_deg, M))
+    return w
+
+
+def _csr_from_pairs_device(rows, cols, M, K, sort_cols=True, seed=0):
+    """(row, col) pairs on the device -> int32 (row_ptr, col_idx): duplicates dropped; columns ascending inside a row, or -- sort_cols = False --
+    in a random order (the reference leaves the order unspecified, util.h:120-129: switches the column strips off, `segments_unsorted`)."""
+    import torch
+
+    key = torch.unique(rows.to(torch.int64) * int(K) + cols.to(torch.int64))      # sorted
+    rows = torch.div(key, int(K), rounding_mode="floor")
+    cols = (key - rows * int(K)).to(torch.int32)
+    del key
+    ptr = torch.zeros(M + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(torch.bincount(rows, minlength=M), 0, out=ptr[1:])
+    assert int(ptr[-1].item()) <= np.iinfo(np.int32).max
+    if not sort_cols:
+        gen = torch.Generator(device=rows.device)
+        gen.manual_seed(int(seed) + 77)
+        r = torch.rand(cols.numel(), generator=gen, device=rows.device, dtype=torch.float64)
+        order = torch.argsort(rows.to(torch.float64) + r * 0.999)               # rows stay grouped, the order inside a row is random
+        cols = cols[order]
+    return ptr.to(torch.int32), cols
+
+
+def csr_dcsbm_device(M, nnz_target, max_deg, device, alpha=1.5, mean_comm=2048, p_in=0.8, order="community", symmetric=True, sort_cols=True,
+                     seed=SEED_STRUCT):
+    """Degree-corrected stochastic block model: expected degrees with a power-law profile (longest row ~ max_deg), communities of random sizes
+    (mean `mean_comm`), every edge's second endpoint drawn -- in proportion to the expected degrees -- inside the first endpoint's community with
+    probability p_in and from the whole graph otherwise; symmetric = True adds the transposed edges (A = A^T: hub rows are hub columns).
+    order: "community" -- a community's vertices have consecutive ids (what a BFS / RCM / partitioner ordering of such a graph yields);
+           "shuffled"  -- ids permuted at random (no locality; the degree correlation stays);
+           "degree"    -- vertices sorted by expected degree, hubs first (crawl order of many public datasets; un-permuted R-MAT looks like this).
+    alpha = 0: all expected degrees equal (a plain SBM: dense diagonal blocks + sparse off-diagonal).
+    Returns device int32 (row_ptr, col_idx)."""
+    import torch
+
+    dev = torch.device(device)
+    mean_deg = nnz_target / M
+    if alpha > 0:
+        w = _powerlaw_weights(M, mean_deg, max_deg, alpha, seed, 11)
+    else:
+        w = np.full(M, mean_deg)
+    g = _rng(seed, 12)
+    n_comm = max(1, int(round(M / mean_comm)))
+    cuts = np.sort(g.choice(np.arange(1, M), size=n_comm - 1, replace=False)) if n_comm > 1 else np.empty(0, dtype=np.int64)
+    comm_beg = np.concatenate([[0], cuts]).astype(np.int64)
+    comm_end = np.concatenate([cuts, [M]]).astype(np.int64)
+    w_d = torch.from_numpy(w).to(dev)
+    sizes = torch.from_numpy(comm_end - comm_beg).to(dev)
+    comm_of = torch.repeat_interleave(torch.arange(n_comm, device=dev), sizes)
+    # every vertex splits its expected degree into an intra-community share and a global share.  A vertex whose expected degree is a large part of its
+    # community cannot keep p_in of its edges inside (they would be duplicates): its share shrinks -- hubs connect everywhere, like the real ones.
+    q = p_in * torch.clamp(0.25 * sizes[comm_of].to(torch.float64) / w_d, max=1.0)
+    wa, wb = w_d * q, w_d * (1.0 - q)
+    del q
+    E = int(nnz_target // 2) if symmetric else int(nnz_target)
+    E_in = int(round(E * float(wa.sum().item()) / float(w_d.sum().item())))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+
+    def draw(cw, lo, hi, n):                            # n vertices in proportion to the weights behind the cumulative sums cw, inside [lo, hi)
+        u = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
+        return torch.searchsorted(cw, lo + u * (hi - lo)).clamp_(max=M - 1)
+
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+    # intra-community edges: first endpoint in proportion to wa (picks the community too), second one in proportion to wa inside that community
+    ca = torch.cumsum(wa, 0)
+    ca0 = torch.cat([zero.reshape(1), ca])              # ca0[v] = weight in front of vertex v
+    i_in = draw(ca, zero, ca[-1], E_in)
+    c = comm_of[i_in]
+    j_in = draw(ca, ca0[torch.from_numpy(comm_beg).to(dev)[c]], ca0[torch.from_numpy(comm_end).to(dev)[c]], E_in)
+    del c, ca, ca0
+    # global edges: both endpoints in proportion to wb
+    cb_ = torch.cumsum(wb, 0)
+    i_gl = draw(cb_, zero, cb_[-1], E - E_in)
+    j_gl = draw(cb_, zero, cb_[-1], E - E_in)
+    del cb_
+    i, j = torch.cat([i_in, i_gl]), torch.cat([j_in, j_gl])
+    del i_in, j_in, i_gl, j_gl
+    if order == "shuffled":
+        perm = torch.from_numpy(g.permutation(M)).to(dev)
+        i, j = perm[i], perm[j]
+    elif order == "degree":
+        rank = torch.empty(M, dtype=torch.int64, device=dev)
+        rank[torch.argsort(w_d, descending=True, stable=True)] = torch.arange(M, device=dev)
+        i, j = rank[i], rank[j]
+    elif order != "community":
+        raise ValueError(order)
+    if symmetric:
+        i, j = torch.cat([i, j]), torch.cat([j, i])
+    return _csr_from_pairs_device(i, j, M, M, sort_cols=sort_cols, seed=seed)
+
+
+def csr_dataset_structured_device(name, device, order="community", sort_cols=True, p_in=0.8):
+    """The SHAPE of one of the reference's datasets (rows, nonzeros, longest row: DATASET_SHAPES) with the STRUCTURE csr_dcsbm_device gives it."""
+    M, nnz_target, max_deg = DATASET_SHAPES[name]
+    mean_comm = 256 if M < 10_000 else 2048
+    return csr_dcsbm_device(M, nnz_target, min(max_deg, M), device, mean_comm=mean_comm, p_in=p_in, order=order, sort_cols=sort_cols,
+                            seed=sum(map(ord, name)) % 1000 + 1)
+
+
+def csr_rmat_device(scale, device, edge_factor=32, a=0.57, b=0.19, c=0.19, seed=SEED_STRUCT, sort_cols=True):
+    """csr_rmat's model drawn on the device (its own random stream: not the same edges), vertex ids NOT permuted: vertex 0 is the largest hub, ids with few
+    set bits are hubs, and hub rows are hub columns -- the structure a Graph500 generator has before its final relabelling."""
+    import torch
+
+    dev = torch.device(device)
+    M = 1 << scale
+    E = M * edge_factor
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    rows = torch.zeros(E, dtype=torch.int64, device=dev)
+    cols = torch.zeros(E, dtype=torch.int64, device=dev)
+    for _ in range(scale):
+        r = torch.rand(E, generator=gen, device=dev)
+        rows = (rows << 1) | (r >= a + b)
+        cols = (cols << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c))
+    return _csr_from_pairs_device(rows, cols, M, M, sort_cols=sort_cols, seed=seed)
+
+
+def csr_reorder_rcm(ptr, idx):
+    """A true reverse Cuthill-McKee ordering (scipy, host) of a graph given as numpy CSR: rows and columns relabelled by the same permutation, columns
+    re-sorted.  For the small dataset shapes (seconds up to a few million nonzeros); the larger ones use order = "community" instead."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+    M = ptr.size - 1
+    A = sp.csr_matrix((np.ones(idx.size, dtype=np.int8), idx, ptr), shape=(M, M))
+    perm = reverse_cuthill_mckee(A, symmetric_mode=False)
+    A = A[perm][:, perm].tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
 def make_values(nnz, seed=SEED_VALS):
     return normal_f32(nnz, seed, 0)
 

@@ -332,3 +332,42 @@ def test_count_bitdiff_sees_planted_differences(device):
     assert nd == 1 and mx == float("inf")
     a2.view(torch.int32)[n - 1] = 0x7FC00002            # same NaN bits on both sides: no difference
     assert count_bitdiff(a2, b2) == (0, 0.0)
+
+
+def test_long_rows_device_generator_full_size_against_the_reference_kernel(device, oracle):
+    """`bench.py`'s `also.LONG_ROWS` input (synth.csr_long_rows_device: 300-700 nonzeros in every row, columns ascending over all K, built on the device)
+    had no parity test of its own: the column strips were checked at full size only through the reddit-shaped graph at N = 32.
+    Here at the bench's size and width: whole C against spmm_kernel_ref itself, strips in force, both strip builders, and the tables' hash equal."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd.spmm import count_bitdiff, fill_normal
+
+    M, N = 1 << 17, 128
+    d_ptr, d_idx = synth.csr_long_rows_device(M, device)
+    nnz = int(d_idx.numel())
+    deg = torch.diff(d_ptr)
+    assert int(deg.min()) >= 300 and int(deg.max()) <= 700
+    d_val = torch.empty(nnz, dtype=torch.float32, device=device)
+    fill_normal(d_val, 124, 0, 0.0, 0.1)
+    d_B = torch.empty(M * N, dtype=torch.float32, device=device)
+    fill_normal(d_B, 125, 0, 0.0, 0.1)
+    d_B = d_B.view(M, N)
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    hashes = []
+    for builder in (0, 1):
+        d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), N)
+        op.set_option("col_strips_builder", builder)
+        op.preprocess(d_B, d_C)
+        assert op.get_option("n_col_strips") >= 8 and op.get_option("segments_unsorted") == 0 and op.get_option("n_chunks") == M
+        assert op.get_option("segment_nnz") == nnz
+        op.run(d_B, d_C)
+        op.run(d_B, d_C)
+        ndiff, maxabs = count_bitdiff(d_C, d_R)
+        assert ndiff == 0 and maxabs == 0.0, (builder, ndiff)
+        hashes.append(op.get_option("col_strips_table_hash"))
+        print(f"LONG_ROWS builder {builder}: preprocess {op.get_option('preprocess_us')} us, strips {op.get_option('n_col_strips')}")
+    assert hashes[0] == hashes[1] != 0

@@ -1687,3 +1687,88 @@ def test_column_strips_inside_a_captured_graph(device, oracle, overlap):
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+
+
+# ---- round 5 -----------------------------------------------------------------------------------------------------------------------
+def test_run_on_a_non_blocking_stream_straight_after_preprocess(device, oracle):
+    """mi_spmm.h: preprocess synchronises.  Its last launches (the strip tables, round 4: build_col_strips on the null stream, nothing behind it when the
+    hubs were folded and no side stream was made) used to be still in flight when it returned; a run() on a hipStreamNonBlocking stream -- every
+    torch.cuda.Stream(), the multi-GPU step's streams -- is not ordered behind the null stream and could read a half-written table.
+    No synchronize between preprocess and run here, many handles in a row so that a race would have its chances."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M = K = 30000
+    N = 64
+    ptr, idx = _strip_case(M, K, 150, 350, seed=51)
+    vals = synth.normal_f32(idx.size, 52)
+    B = synth.normal_f32(K * N, 53).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    s = torch.cuda.Stream(device=device)          # hipStreamNonBlocking
+    torch.cuda.synchronize()
+    for builder in (0, 1, 0, 1, 0, 0):
+        d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
+        op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N)
+        for k, v in {"col_strips": 16, "hub_overlap": 0, "segment_overlap": 0, "col_strips_builder": builder}.items():
+            op.set_option(k, v)
+        op.preprocess(d_B, d_C)
+        with torch.cuda.stream(s):
+            op.run(d_B, d_C)
+        s.synchronize()
+        assert op.get_option("n_col_strips") == 16
+        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)), builder
+
+
+def test_strip_builders_agree(device, oracle):
+    """Round 5's one-pass strip builder (strip_segments: a wave strides a segment's columns once; a lane whose column and its left neighbour's lie in
+    different strips has found where the strips in between begin) writes the tables of round 4's survey + S binary searches per segment, record for
+    record: same FNV hash over the table, for several strip counts, duplicate columns, K not a multiple of S, segments shorter than S, both plan builders."""
+    M, K, N = 5000, 7001, 32
+    ptr, idx = _strip_case(M, K, 0, 200, seed=61, hubs=(900, 3000, 7001))
+    for r in range(0, M, 5):                       # equal neighbours
+        b, e = ptr[r], ptr[r + 1]
+        if e - b > 4:
+            idx[b + 2] = idx[b + 1]
+            idx[e - 1] = idx[e - 2]
+    vals = synth.normal_f32(idx.size, 62)
+    B = synth.normal_f32(K * N, 63).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    for S in (2, 3, 7, 13, 32, 64):
+        for gpu_pre in (1, 0):
+            h = []
+            for builder in (0, 1):
+                C, op = run_spmm(device, ptr, idx, vals, B, options={"col_strips": S, "medium_row_threshold": 8, "long_row_threshold": 1 << 30,
+                                                                     "gpu_preprocess": gpu_pre, "col_strips_builder": builder})
+                assert op.get_option("n_col_strips") == S and op.get_option("segments_unsorted") == 0
+                assert op.get_option("segment_nnz") == int(np.diff(ptr)[np.diff(ptr) > 8].sum())
+                assert np.array_equal(bits(C), bits(exp)), (S, gpu_pre, builder)
+                h.append(op.get_option("col_strips_table_hash"))
+            assert h[0] == h[1] and h[0] != 0, (S, gpu_pre, h)
+    # an unsorted segment: both builders say so and neither table is used
+    idx_bad = idx.copy()
+    r = int(np.argmax(np.diff(ptr)))
+    idx_bad[ptr[r] + 10], idx_bad[ptr[r] + 400] = idx_bad[ptr[r] + 400], idx_bad[ptr[r] + 10]
+    for builder in (0, 1):
+        C, op = run_spmm(device, ptr, idx_bad, vals, B, options={"col_strips": 7, "medium_row_threshold": 8, "long_row_threshold": 1 << 30, "col_strips_builder": builder})
+        assert op.get_option("n_col_strips") == 1 and op.get_option("segments_unsorted") == 1 and op.get_option("col_strips_table_hash") == 0
+        assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx_bad, vals, B)))
+
+
+def test_fold_falls_back_to_the_hub_plan_when_a_former_hub_is_unsorted(device, oracle):
+    """the folded plan (no hubs: every row a stripped segment) surveys the former hub rows for the first time.  One of them with columns
+    out of order switches the strips off -- and used to leave a 3 000-nonzero row as ONE unstripped segment chain with no hub kernel.  Now the plan with
+    hubs is built again: strips for the (sorted) segments, the hub kernel for the hubs."""
+    M = K = 65536
+    N = 128
+    ptr, idx = _strip_case(M, K, 150, 350, seed=17, hubs=(3000, 3000, 2500))
+    deg = np.diff(ptr)
+    r = int(np.argmax(deg))
+    idx[ptr[r] + 3], idx[ptr[r] + 2000] = idx[ptr[r] + 2000], idx[ptr[r] + 3]
+    vals = synth.normal_f32(idx.size, 21)
+    B = synth.normal_f32(K * N, 22).reshape(K, N)
+    C, op = run_spmm(device, ptr, idx, vals, B)
+    assert op.get_option("n_hub_rows") >= 1 and op.get_option("long_row_threshold") < 1 << 30
+    assert op.get_option("n_col_strips") >= 2 and op.get_option("segments_unsorted") == 0
+    assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B)))
