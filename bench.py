@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HUB_CLOCK_HZ = 2.4e9         # MI355X peak engine clock: cycles of the `chain` bound (also.AM32)
 COLS_PER_GPU = 128
 
 # The contract: rank 0 prints ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout at
@@ -95,6 +96,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="N=1, C1: skip the `also` object (C2, C4 and C1 at N=1024, timed after the headline)")
     ap.add_argument("--no-strong-reference", action="store_true", help="N>1: skip the one-GPU-all-columns reference timing")
+    ap.add_argument("--no-link-probe", action="store_true", help="N>1: skip the link probe (peer copies after the timed region: multi_gpu_breakdown.links)")
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the workload the CPU baseline runs (default: all for C1)")
     ap.add_argument("--check", action="store_true", help="verify a row sample against the oracle after timing")
     ap.add_argument("--sweep", default=None, help="tuning sweep name: knobs")
@@ -181,7 +183,9 @@ class Watchdog:
     within its bound, rank 0 prints the contract line it has IN HAND (a complete measurement of the safe schedule, with
     `exchange_watchdog` saying what hung) and every rank leaves with os._exit -- a decision to stop, never a re-exec of a
     process that has initialised the GPU, and never a retry.  Exit code: MI_SPMM_WATCHDOG_EXIT (default 0: the line in hand
-    is a valid measurement and the hang is reported inside it; non-zero if no line is in hand yet)."""
+    is a complete, valid measurement of the safe schedule and a non-zero code would make a driver discard it with the run; the stop is
+    reported at the top level of that line -- "watchdog_fired": <section> -- and on stderr with every thread's traceback; set the variable
+    to make the same stop read as a failure.  Non-zero (3) whenever no line is in hand yet)."""
 
     def __init__(self, rank):
         import threading
@@ -236,6 +240,7 @@ class Watchdog:
                 elif self.printed:
                     code = 0                       # the final line is out already (a hang in tear-down)
                 elif self.rank == 0 and line is not None:
+                    line["watchdog_fired"] = label        # top level: a reader of the run record sees the stop without looking inside anything
                     line["exchange_watchdog"] = {"fired_in": label, "note": "that section hung (no exception, no completion); this line is the "
                                                  "measurement in hand from before it; the process left with os._exit"}
                     emit_line(line)
@@ -683,6 +688,54 @@ def main():
       if rank == 0:
           wd.set_line(build_line())
 
+    # N > 1: what the links deliver (SURVEY.md H3 "measure link bandwidth first") -- outside the timed region, under the watchdog: a probe
+    # that hangs costs the probe, not the line.  Plain device-to-device copies into the peers' C (mapped through HIP IPC), one peer at a time, then all at once.
+    if multi and sharded is not None and not args.no_link_probe:
+        wd.arm("link probe (peer copies)", wd_bound)
+        links = None
+        ok = 1.0
+        try:
+            if os.environ.get("MI_SPMM_FORCE_HANG_EXCHANGE") == "link_probe":      # tests: a probe that neither finishes nor throws
+                while True:
+                    time.sleep(3600)
+            if share:       # no communicator between ranks that share a GPU: the probe's barriers go through the host
+                sharded.set_host_barrier(lambda: (torch.cuda.synchronize(), dist.barrier()))
+            if R["exchange"] not in needs_peers:
+                sharded.set_peers(d_Cfull)
+        except Exception as e:
+            print(f"[bench] rank {rank}: link probe unavailable: {e!r}", file=sys.stderr, flush=True)
+            ok = 0.0
+        if agree(ok, dist.ReduceOp.MIN) >= 1.0:          # the probe is collective: either every rank enters it or none does
+            try:
+                # one process per GPU on one node, every device visible: rank q runs on device q (LOCAL_RANK); ranks that share a GPU have no link between them
+                pdev = [-1] * world if share or torch.cuda.device_count() < world else list(range(world))
+                links = sharded.link_probe(d_Cfull, 256 << 20, pdev)
+            except Exception as e:
+                links = {"error": repr(e)[:200]}
+            if share:
+                sharded.set_host_barrier(None)
+            step()                   # the probe wrote junk into every C: leave a complete one behind
+            torch.cuda.synchronize()
+            barrier()
+        if links is not None and "error" not in links:
+            # the slowest rank's view of every number (a step ends when the slowest rank's exchange does)
+            links["all_peers_GBs_min_over_ranks"] = round(agree(links["all_peers_GBs"], dist.ReduceOp.MIN), 1)
+            slowest = min((x for q, x in enumerate(links["per_peer_GBs"]) if q != rank), default=0.0)
+            links["per_peer_GBs_min_over_ranks"] = round(agree(slowest, dist.ReduceOp.MIN), 1)
+            moved = (world - 1) * M * n_loc * 4
+            rate = links["all_peers_GBs_min_over_ranks"]
+            links["link_bound_ms"] = round(moved / (rate * 1e9) * 1e3, 4) if rate > 0 else None
+            links["link_bound_note"] = ("bytes a GPU sends per step (world - 1 column blocks) / the rate its links delivered together in the probe (slowest rank): "
+                                        "the exchange cannot finish sooner on these links; compare with ms_per_step and exchange_only_ms")
+            if share:
+                links["note"] = "ranks share one GPU: the copies never left the device; the numbers exercise the code path, they are not link rates"
+        if R["breakdown"] is None:
+            R["breakdown"] = {}
+        R["breakdown"]["links"] = links
+        wd.disarm()
+        if rank == 0:
+            wd.set_line(build_line())
+
     # N > 1: what ONE GPU needs for all N_total columns (the north star's ">= 6x at 8 GPUs on N = 1024" is against this)
     if multi and rank == 0 and not args.no_strong_reference:
         wd.arm("one-GPU strong reference", 2 * wd_bound)
@@ -755,7 +808,7 @@ def also_configs(args, dev, c1_tensors, M):
 
     M_c1 = M
 
-    def run_one(tag, d_ptr, d_idx, n, nnz, extra, M=None):
+    def run_one(tag, d_ptr, d_idx, n, nnz, extra, M=None, chain=False):
         M = M_c1 if M is None else M
         d_val = torch.empty(nnz, dtype=torch.float32, device=dev)
         fill_normal(d_val, synth.SEED_VALS)
@@ -798,6 +851,37 @@ def also_configs(args, dev, c1_tensors, M):
                     "traffic": traffic, "traffic_source": src, "launches_per_step": op.get_option("n_launches"),
                     "block_items": {k: op.get_option(k) for k in ("n_block_groups", "n_block_pieces", "n_block_items",
                                                                   "n_block_shared_items", "n_block_passes")}}
+        elif chain:
+            # one row's dependent fma chain is the step (am-shaped kLen 32: a 142 153-nonzero row in a 5.8 M-nonzero matrix): the bound is the chain, not bytes.
+            # floor: ~5 cycles per dependent v_fmac_f32 (scripts/experiments/fma_chain_micro.hip); achieved: the WHOLE step's time over the
+            # longest row (the hub kernel runs beside the rows kernel on its side stream; launch and fork / join included) -- an upper bound on the chain's cost
+            longest = op.get_option("max_row_nnz")
+            cyc = ms * 1e-3 * HUB_CLOCK_HZ / max(1, longest)
+            gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
+            roof = {"bound": "chain", "bound_detail": "the longest row's stored-order fma chain (spmm_ref.cu:10-14 allows no other order): floor ~5 cycles per nonzero "
+                    "of that row at 2.4 GHz; achieved = step time x clock / longest row", "kernel": "mi::spmm_hub", "achieved": round(cyc, 2), "peak": 5.0,
+                    "unit": "cycles per nonzero of the longest row (lower is better; frac = floor / achieved)", "frac": round(5.0 / cyc, 4),
+                    "cycles_per_nonzero": round(cyc, 2), "floor_cycles": 5.0, "longest_row": int(longest), "ns_per_nonzero": round(ms * 1e6 / max(1, longest), 3),
+                    "chain_floor_ms": round(5.0 * longest / HUB_CLOCK_HZ * 1e3, 4), "bytes_alg": model["bytes_alg"], "bytes_min": model["bytes_min"],
+                    "GBs_on_bytes_alg": round(gbs, 1), "bytes_floor_ms": round(model["bytes_alg"] / 8e12 * 1e3, 4),
+                    "traffic": traffic, "traffic_source": src, "launches_per_step": op.get_option("n_launches"), "n_hub_rows": op.get_option("n_hub_rows")}
+        elif 4.0 * M * n <= 256 * 1048576:
+            # B fits the Infinity Cache (and, strip by strip, an XCD's L2): the gather model's bytes are NOT what the memory system moves, so a fraction of the
+            # HBM peak on them can exceed 1 (round 4 printed 2.25 under "hbm").  The honest bound: what crossed the L2 <-> fabric side (PMC) over the step,
+            # against the fabric's 8 TB/s; without counters, the gather model against the L2-resident gather rate of the guide (18 TB/s).
+            gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
+            if traffic is not None:
+                ach = traffic / (ms * 1e-3) / 1e9
+                roof = {"bound": "fabric", "bound_detail": "B is cache-resident (4 K N <= 256 MiB): measured L2<->fabric bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) "
+                        "per step over this run's step time, against the fabric's 8 TB/s", "peak": HBM_PEAK_GBS, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+            else:
+                roof = {"bound": "l2_gather", "bound_detail": "B is cache-resident (4 K N <= 256 MiB) and no counters are at hand: gather-model bytes against the "
+                        "L2-resident gather rate (MI355X_MICROARCH.md \"Indexed rows\": 16.8-18.8 TB/s chip-wide)", "peak": 18000.0, "achieved": round(gbs, 1),
+                        "frac": round(gbs / 18000.0, 4)}
+            roof.update({"kernel": "mi::spmm_chunks (column strips) + mi::spmm_rows_v2", "unit": "GB/s", "achieved_alg": round(gbs, 1),
+                         "achieved_alg_note": "gather-model bytes / step time: served mostly by L2 and the Infinity Cache, not a fraction of any memory peak",
+                         "b_bytes": int(4 * M * n), "bytes_alg": model["bytes_alg"], "bytes_min": model["bytes_min"], "traffic": traffic, "traffic_source": src,
+                         "launches_per_step": op.get_option("n_launches")})
         else:
             gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "bound_detail": "l2_fabric (gather model): algorithmic bytes over the L2<->fabric path, Infinity-Cache hits included",
@@ -808,7 +892,8 @@ def also_configs(args, dev, c1_tensors, M):
         out = {"config": f"{tag}: {extra}, M=K={M}, nnz={nnz}, N={n} fp32", "ms_per_step": round(ms, 4), "steps": n_steps,
                "value": round(flops / (ms * 1e-3) / 1e9, 2), "unit": "GFLOP/s", "preprocess_ms": round(pre_ms, 2), "roofline": roof,
                "summation_order": ("exact (stored order on every row)" if not op.get_option("split_long_rows") else "split"),
-               "options": {k: op.get_option(k) for k in ("long_row_threshold", "n_hub_rows", "n_medium_rows", "lanes_per_row", "tile_cols", "n_col_strips")}}
+               "options": {k: op.get_option(k) for k in ("long_row_threshold", "n_hub_rows", "n_medium_rows", "lanes_per_row", "tile_cols", "n_col_strips",
+                                                          "hub_slice", "max_row_nnz")}}
         del op, d_val, d_B, d_C
         torch.cuda.empty_cache()
         return out
@@ -836,6 +921,19 @@ def also_configs(args, dev, c1_tensors, M):
         del d_ptr, d_idx
     except Exception as e:
         res["LONG_ROWS"] = {"error": repr(e)[:200]}
+    try:
+        # the hub kernel in the driver's line (VERDICT r4 #3a): am-shaped kLen 32 -- one row of 142 153 nonzeros in a 5.8 M-nonzero matrix, chain-bound
+        if M == (1 << 20):
+            ptr, idx = synth.csr_dataset_shaped("am")
+        else:       # down-sized runs (tests): the same shape in proportion
+            Ma = max(4096, M * 881_680 // (1 << 20))
+            ptr, idx = synth.csr_powerlaw(Ma, 6.43, max(512, min(Ma, Ma * 154_828 // 881_680)), seed=sum(map(ord, "am")) % 1000 + 1, force_max=True)
+        d_ptr, d_idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+        res["AM32"] = run_one("AM32", d_ptr, d_idx, 32, int(idx.size), f"am-shaped (synth.DATASET_SHAPES: longest row {int(np.diff(ptr).max())}, the hub kernel's case)",
+                              M=ptr.size - 1, chain=True)
+        del d_ptr, d_idx, ptr, idx
+    except Exception as e:
+        res["AM32"] = {"error": repr(e)[:200]}
     try:
         d_ptr, d_idx, nnz = c1_tensors
         res["C1_N1024"] = run_one("C1_N1024", d_ptr, d_idx, 1024, nnz, "C1's CSR, the one-GPU leg of configs[3]")

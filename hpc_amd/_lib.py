@@ -42,7 +42,8 @@ _lib = None
 
 # The kernel sources a measured profile describes: profiles/traffic_latest.json stores this hash beside the counters
 # (scripts/summarize_prof.py) and bench.py compares it with the tree it runs from ("traffic_stale").
-KERNEL_SOURCES = ("spmm_kernels.hpp", "mi_spmm.hip", "hub_chain_asm.inc")
+# (round 5: plan.hpp / plan_types.hpp / preprocess_gpu.hip decide strip counts, thresholds and launch sets -- re-tuning a rule changes the measured traffic too)
+KERNEL_SOURCES = ("spmm_kernels.hpp", "mi_spmm.hip", "hub_chain_asm.inc", "plan.hpp", "plan_types.hpp", "preprocess_gpu.hip")
 
 
 def kernel_sources_sha256():

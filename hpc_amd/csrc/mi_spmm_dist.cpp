@@ -616,6 +616,89 @@ int mi_spmm_dist_run_exchange_only(mi_spmm_dist *d, float *d_C_full, void *strea
     return step(d, nullptr, d_C_full, (hipStream_t)stream, false, true);
 }
 
+// "measure link bandwidth first".  What one link delivers, what all of a GPU's links deliver together, and what kind of links they are --
+// the one unknown DESIGN.md's ceiling for the 8-GPU step swings on (76.8 vs 153 GB/s per direction).  Plain device-to-device copies from the front of the
+// rank's C_full into the front of each peer's (mapped by set_peers / set_peer_pointers): set-up time, outside any timed region; C_full is scratch afterwards.
+int mi_spmm_dist_link_probe(mi_spmm_dist *d, float *d_C_full, int64_t nbytes, const int32_t *peer_device, double *per_peer_gbs,
+                            double *all_peers_gbs, int32_t *link_type, int32_t *hops)
+{
+    if (!good(d) || !d_C_full || !per_peer_gbs || !all_peers_gbs || !link_type || !hops) return MI_SPMM_EINVAL;
+    if ((int)d->peer_C.size() != d->world || d->exported_C != d_C_full) return MI_SPMM_ESTATE;      // set_peers first
+    const int64_t have = (int64_t)d->M * d->N_total * 4;
+    if (nbytes <= 0 || nbytes > have) nbytes = have < ((int64_t)256 << 20) ? have : ((int64_t)256 << 20);
+    *all_peers_gbs = 0.0;
+    for (int q = 0; q < d->world; ++q) { per_peer_gbs[q] = 0.0; link_type[q] = -1; hops[q] = -1; }
+    if (d->world == 1 || nbytes <= 0) return 0;
+    MI_TRY(ensure_streams(d));
+    MI_TRY(ensure_push_streams(d));
+    // topology as the runtime reports it (needs the peers' device ordinals as THIS process sees them; -1 / null: unknown, e.g. one visible device per process)
+    int me = -1, ndev = 0;
+    HIP_TRY(hipGetDevice(&me));
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    for (int q = 0; q < d->world && peer_device; ++q) {
+        const int pd = peer_device[q];
+        if (q == d->rank || pd < 0 || pd >= ndev || pd == me) continue;
+        uint32_t lt = 0, hc = 0;
+        if (hipExtGetLinkTypeAndHopCount(me, pd, &lt, &hc) == hipSuccess) { link_type[q] = (int32_t)lt; hops[q] = (int32_t)hc; }
+        else (void)hipGetLastError();
+    }
+    // every rank at the same point before each shift: the step's own barrier (communicator all-reduce, else the host's callback), then the host waits for it
+    auto align = [&]() -> int {
+        if (d->comm) { MI_TRY(device_barrier(d, d->s_comm)); HIP_TRY(hipStreamSynchronize(d->s_comm)); }
+        else if (d->host_barrier) d->host_barrier(d->host_barrier_ctx);
+        return 0;
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MI_SPMM_ENOMEM; }
+    int rc = 0;
+    auto fail = [&](int code) { rc = code; };
+    // one peer at a time: shift k, every rank sends to rank + k while it receives from rank - k (what one link carries in one direction while its reverse
+    // direction and every other GPU's links are busy too).  Best of three: the first copy also pays the mapping's first touch.
+    for (int k = 1; k < d->world && rc == 0; ++k) {
+        const int to = (d->rank + k) % d->world;
+        if ((rc = align()) != 0) break;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3 && rc == 0; ++rep) {
+            hipError_t e = hipEventRecord(e0, d->s_push[0]);
+            if (e == hipSuccess) e = hipMemcpyAsync(d->peer_C[(size_t)to], d_C_full, (size_t)nbytes, hipMemcpyDeviceToDevice, d->s_push[0]);
+            if (e == hipSuccess) e = hipEventRecord(e1, d->s_push[0]);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { fail((int)e); break; }
+            if (ms < best) best = ms;
+        }
+        if (rc == 0 && best > 0.f) per_peer_gbs[to] = (double)nbytes / ((double)best * 1e-3) / 1e9;
+    }
+    // all peers at once, one stream per peer (the peer2d step's streams): what the GPU's links deliver together, outbound
+    if (rc == 0 && (rc = align()) == 0) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3 && rc == 0; ++rep) {
+            hipError_t e = hipEventRecord(e0, d->s_comm);
+            for (int k = 1; k < d->world && e == hipSuccess; ++k) {
+                const int to = (d->rank + k) % d->world;
+                hipStream_t s = d->s_push[(size_t)(k - 1)];
+                e = hipStreamWaitEvent(s, e0, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(d->peer_C[(size_t)to], d_C_full, (size_t)nbytes, hipMemcpyDeviceToDevice, s);
+                if (e == hipSuccess) e = hipEventRecord(d->ev_pushed[(size_t)(k - 1)], s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(d->s_comm, d->ev_pushed[(size_t)(k - 1)], 0);
+            }
+            if (e == hipSuccess) e = hipEventRecord(e1, d->s_comm);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { fail((int)e); break; }
+            if (ms < best) best = ms;
+        }
+        if (rc == 0 && best > 0.f) *all_peers_gbs = (double)(d->world - 1) * (double)nbytes / ((double)best * 1e-3) / 1e9;
+    }
+    if (rc == 0) rc = align();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int64_t mi_spmm_dist_ipc_exportable_bytes(int64_t nbytes)
 {
     if (nbytes < 0) return MI_SPMM_EINVAL;

@@ -255,6 +255,7 @@ _DIST_SIGNATURES = {
     "mi_spmm_dist_export_c": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_ipc_exportable_bytes": (_C.c_int64, [_C.c_int64]),
     "mi_spmm_dist_set_peers": (_C.c_int, [_P, _P, _P, _C.POINTER(_C.c_int64)]),
+    "mi_spmm_dist_link_probe": (_C.c_int, [_P, _P, _C.c_int64, _P, _P, _P, _P, _P]),
     "mi_spmm_dist_set_peer_pointers": (_C.c_int, [_P, _P, _P]),
     "mi_spmm_dist_export_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
     "mi_spmm_dist_set_peer_staging": (_C.c_int, [_P, _P, _C.POINTER(_C.c_int64)]),
@@ -324,6 +325,11 @@ def alloc_c_full(M, n_total, device, fill=None):
     if fill is not None:
         C.fill_(fill)
     return C
+
+
+def L_bytes(layout):
+    """floats in a rank's C_full"""
+    return int(layout.M) * int(layout.N_total)
 
 
 class NativeColumnShardedSpMM:
@@ -418,6 +424,22 @@ class NativeColumnShardedSpMM:
         ptrs = (_P * self.layout.world)(*[_P(t.data_ptr()) for t in all_C_full])
         _dcheck(self._lib.mi_spmm_dist_set_peer_pointers(self._d, _P(C_full.data_ptr()), ptrs), "mi_spmm_dist_set_peer_pointers")
         self._peers_of = list(all_C_full)
+
+    LINK_TYPES = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi", -1: "unknown"}
+
+    def link_probe(self, C_full, nbytes=256 << 20, peer_devices=None):
+        """Collective, after set_peers / set_peer_tensors, outside any timed region: what the links to the peers deliver (mi_spmm_dist_link_probe).
+        C_full holds junk afterwards.  Returns {"per_peer_GBs": [...], "all_peers_GBs": x, "link_type": [...], "hops": [...], "bytes": n}."""
+        W = self.layout.world
+        per = (_C.c_double * W)()
+        allp = _C.c_double(0.0)
+        lt = (_C.c_int32 * W)()
+        hp = (_C.c_int32 * W)()
+        pd = (_C.c_int32 * W)(*[int(x) for x in peer_devices]) if peer_devices is not None else None
+        _dcheck(self._lib.mi_spmm_dist_link_probe(self._d, _P(C_full.data_ptr()), int(nbytes), pd, per, _C.byref(allp), lt, hp), "mi_spmm_dist_link_probe")
+        return {"per_peer_GBs": [round(float(x), 1) for x in per], "all_peers_GBs": round(float(allp.value), 1),
+                "link_type": [self.LINK_TYPES.get(int(x), str(int(x))) for x in lt], "hops": [int(x) for x in hp],
+                "bytes": int(min(nbytes, 4 * L_bytes(self.layout)))}
 
     def set_peer_staging(self):
         """Collective (exchange="ipc_pull").  Every rank exports its two staging buffers; the table goes to the library."""

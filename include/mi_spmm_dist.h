@@ -91,6 +91,17 @@ int mi_spmm_dist_export_c(mi_spmm_dist *d, float *d_C_full, void *handle_out, in
 int64_t mi_spmm_dist_ipc_exportable_bytes(int64_t nbytes);
 int mi_spmm_dist_set_peers(mi_spmm_dist *d, float *d_C_full, const void *handles, const int64_t *offsets);
 
+/* Link probe ("measure link bandwidth first"; no reference counterpart).  After set_peers / set_peer_pointers, at set-up time, COLLECTIVE
+ * (every rank calls it; the shifts are separated by the step's own barrier: the communicator's all-reduce, else the host barrier callback).  Copies nbytes
+ * (<= 0 or too large: min(256 MiB, the size of C_full)) device-to-device from the front of this rank's C_full into the front of a peer's:
+ *   per_peer_gbs[world]  GB/s to peer q, measured while every rank sends to rank + k and receives from rank - k (one link, both directions busy); own entry 0
+ *   *all_peers_gbs       GB/s out of this GPU with all world - 1 copies in flight at once (one stream per peer)
+ *   link_type[world], hops[world]   hipExtGetLinkTypeAndHopCount(this device, peer_device[q]) (HSA_AMD_LINK_INFO_TYPE_*: 2 = PCIe, 4 = xGMI); -1 = unknown.
+ *                        peer_device (world entries, may be NULL): rank q's device ordinal as THIS process sees it, -1 if it does not.
+ * C_full holds junk afterwards (it is the step's output buffer: run a step before reading it).  A probe that hangs is the caller's watchdog's to catch. */
+int mi_spmm_dist_link_probe(mi_spmm_dist *d, float *d_C_full, int64_t nbytes, const int32_t *peer_device, double *per_peer_gbs,
+                            double *all_peers_gbs, int32_t *link_type, int32_t *hops);
+
 /* The same table for a host that drives several ranks from ONE process (one thread or object per GPU, peer access enabled by
  * the host): the peers' C_full as plain device pointers, no IPC.  peer_C_full: world pointers, the rank's own entry ignored. */
 int mi_spmm_dist_set_peer_pointers(mi_spmm_dist *d, float *d_C_full, float *const *peer_C_full);

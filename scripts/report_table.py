@@ -44,6 +44,25 @@ def timed(f, warm, reps):
     return a.elapsed_time(b) / reps / 1e3   # seconds, like the reference's tables
 
 
+def gather_rate(b_bytes):
+    """The gather rate a B of that size allows (MI355X_MICROARCH.md "Indexed rows": rows shared through an XCD's 4 MiB L2 18 TB/s; a table in the Infinity
+    Cache 8.6 TB/s, its L2 share (4 MiB / T) at the L2 rate; beyond 256 MiB the HBM peak, 8 TB/s)."""
+    mib = 1048576.0
+    if b_bytes <= 4 * mib:
+        return 18e12
+    if b_bytes <= 256 * mib:
+        share = 4 * mib / b_bytes
+        return 1.0 / (share / 18e12 + (1.0 - share) / 8.6e12)
+    return 8e12
+
+
+def floor_seconds(M, N, nnz, longest):
+    """What no stored-order kernel on this chip goes below: the longest row's dependent chain (3.2 ns per nonzero in the hub kernel; the hardware floor
+    is ~5 cycles = 2.1 ns), the gather-model bytes at the rate the size of B allows, one kernel launch (~5 us from enqueue to completion)."""
+    bytes_alg = 8.0 * nnz + 4.0 * (M + 1) + 4.0 * N * nnz + 4.0 * M * N
+    return max(longest * 3.2e-9, bytes_alg / gather_rate(4.0 * M * N), 5e-6)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -78,15 +97,20 @@ def main():
             ours.preprocess(d_B, d_C)
             t_ours = timed(lambda: ours.run(d_B, d_C), 3, 10)
             # the same step replayed from the handle's HIP graph ("use_graph" = 1: one hipGraphLaunch instead of 2-4 launches + fork/join)
-            t_graph, same = float("nan"), True
+            t_graph, same, t_graph2 = float("nan"), True, float("nan")
             if "graph" not in skip:
-                d_G = torch.full((M, N), float("nan"), device=dev)
-                ours_g = SpMMOpt(g, N)
-                ours_g.set_option("use_graph", 1)
-                ours_g.preprocess(d_B, d_G)
-                t_graph = timed(lambda: ours_g.run(d_B, d_G), 3, 10)
-                same = bool(torch.equal(d_G.view(torch.int32), d_C.view(torch.int32))) and ours_g.get_option("graph_replays") == 13
-                del ours_g, d_G
+                for mode in (1, 2):     # 1: hipGraphLaunch on the caller's stream; 2 (round 5): on a handle-owned tested stream, ordered into the caller's by two events
+                    d_G = torch.full((M, N), float("nan"), device=dev)
+                    ours_g = SpMMOpt(g, N)
+                    ours_g.set_option("use_graph", mode)
+                    ours_g.preprocess(d_B, d_G)
+                    tg = timed(lambda: ours_g.run(d_B, d_G), 3, 10)
+                    same = same and bool(torch.equal(d_G.view(torch.int32), d_C.view(torch.int32))) and ours_g.get_option("graph_replays") == 13
+                    if mode == 1:
+                        t_graph = tg
+                    else:
+                        t_graph2 = tg
+                    del ours_g, d_G
             vend, t_vend, ok = None, float("nan"), True
             if "vendor" not in skip:
                 vend = SpMMRocSparse(g, N)
@@ -101,17 +125,18 @@ def main():
                 del ro
             rows_out[N].append((name, M, nnz, int(deg.max()), t_vend, t_ours, t_vend / t_ours, t_stud, t_stud / t_ours, ok,
                                 ours.get_option("n_hub_rows"), ours.get_option("n_partial_slots"), ours.get_option("long_row_threshold"),
-                                t_graph, same, ours.get_option("n_launches"), ours.get_option("n_col_strips")))
+                                t_graph, same, ours.get_option("n_launches"), ours.get_option("n_col_strips"), t_graph2,
+                                floor_seconds(M, N, nnz, int(deg.max())), ours.get_option("preprocess_us")))
             del d_B, d_C, d_V, ours, vend
         del d_ptr, d_idx, d_val, g
         torch.cuda.empty_cache()
     print("# Reference-style report table on MI355X (dataset-shaped synthetic graphs; see scripts/report_table.py)\n")
     for N in lens:
         print(f"### `kLen = {N}`\n")
-        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | column strips of the segments | ours with use_graph = 1 (same bits?) | saved by the graph (us) |")
-        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | column strips of the segments | ours with use_graph = 1 (same bits?) | saved by the graph (us) | use_graph = 2: replay on a tested stream | saved (us) | floor (us) | time / floor | preprocess (us) |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
         for r in rows_out[N]:
-            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[16] if r[16] > 1 else '-'} | {r[13]:.6g} ({'same' if r[14] else 'DIFFERENT'}) | {(r[5] - r[13]) * 1e6:.1f} |")
+            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[16] if r[16] > 1 else '-'} | {r[13]:.6g} ({'same' if r[14] else 'DIFFERENT'}) | {(r[5] - r[13]) * 1e6:.1f} | {r[17]:.6g} | {(r[5] - r[17]) * 1e6:.1f} | {r[18] * 1e6:.1f} | {r[5] / r[18]:.2f} | {r[19]} |")
         sp = [r[6] for r in rows_out[N]]
         if sp:
             print(f"\nspeed-up over the vendor library: min {min(sp):.2f}, geometric mean {float(np.exp(np.mean(np.log(sp)))):.2f}, max {max(sp):.2f} "

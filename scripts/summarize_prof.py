@@ -75,8 +75,12 @@ def main():
         key = sys.argv[sys.argv.index("--traffic-key") + 1]
         tp = os.path.join(out, "traffic_latest.json")
         tl = json.load(open(tp)) if os.path.exists(tp) else {}
+        # The commit is only recorded when it describes the sources that were profiled: a dirty tree (round 4 stamped the parent commit of a re-tuned
+        # rule: 11 strips by its plan.hpp, 13 in the profile) gets "dirty-tree" and is identified by kernel_sources_sha256 alone.
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "hpc_amd/csrc", "include"], capture_output=True, text=True).stdout.strip()
         ent = {"source": f"profiles/{tag}_profile.json",
-               "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown",
+               "commit": head if not dirty else f"dirty-tree (parent {head}): see kernel_sources_sha256",
                "hbm_bytes_per_launch": step["traffic_bytes"], "fetch_bytes_x2": step["fetch_bytes_x2"], "write_bytes": step["write_bytes"]}
         sys.path.insert(0, ROOT)
         from hpc_amd._lib import kernel_sources_sha256

@@ -235,7 +235,12 @@ def test_traffic_entries_carry_a_kernel_source_hash_and_bench_flags_stale_ones()
     from hpc_amd._lib import KERNEL_SOURCES, kernel_sources_sha256
 
     here = kernel_sources_sha256()
-    assert here and len(here) == 64 and set(KERNEL_SOURCES) == {"spmm_kernels.hpp", "mi_spmm.hip", "hub_chain_asm.inc"}
+    # (round 5: the plan sources too -- they decide strip counts, thresholds and launch sets, i.e. the traffic a profile measures)
+    assert here and len(here) == 64 and set(KERNEL_SOURCES) == {"spmm_kernels.hpp", "mi_spmm.hip", "hub_chain_asm.inc", "plan.hpp", "plan_types.hpp",
+                                                               "preprocess_gpu.hip"}
+    csrc = os.path.join(ROOT, "hpc_amd", "csrc")
+    on_disk = {f for f in os.listdir(csrc) if f.endswith((".hpp", ".hip", ".inc"))}
+    assert set(KERNEL_SOURCES) == on_disk, on_disk ^ set(KERNEL_SOURCES)       # a new device source must join the hash
     assert bench.traffic_staleness({"kernel_sources_sha256": here})["traffic_stale"] is False
     assert bench.traffic_staleness({"kernel_sources_sha256": "0" * 64})["traffic_stale"] is True
     assert bench.traffic_staleness({})["traffic_stale"] is True                       # entries from before round 4
@@ -246,3 +251,6 @@ def test_traffic_entries_carry_a_kernel_source_hash_and_bench_flags_stale_ones()
         for k in ("source", "commit", "hbm_bytes_per_launch", "N"):
             assert k in ent, (key, k)
         assert os.path.exists(os.path.join(ROOT, ent["source"])), ent["source"]
+        # an entry names a commit only if that commit's sources are what was profiled; a dirty tree is identified by the hash alone (scripts/summarize_prof.py)
+        assert ent["commit"].startswith("dirty-tree") or re.fullmatch(r"[0-9a-f]{7,40}", ent["commit"]), ent["commit"]
+        assert "kernel_sources_sha256" in ent
