@@ -1,6 +1,8 @@
 // spmm_adapter.hpp -- header-only C++ adapter: the reference's operator classes over the C ABI.
 //
-// A harness written against the reference's headers keeps compiling against this one:
+// The OPERATOR side of a harness written against the reference's headers compiles against this one (test/test_spmm.cu:33-36, 39-40, 43, 48-51,
+// 57-60: tests/test_boundary_compiles.py); its own CUDA runtime calls (allocate<T>, cudaMemset, cudaFree, dbg: test_spmm.cu:16-19, 26, 37-38, 41) are
+// the caller's to port:
 //   struct CSR                      PA4/workspace/include/util.h:120-129
 //   class SpMM (abstract)           PA4/workspace/include/spmm_base.h:8-46
 //   class SpMMOpt : public SpMM     PA4/workspace/include/spmm_opt.h:12-29  (the drop-in)
@@ -115,7 +117,7 @@ private:
 // configuration: every row, whatever its length, is one fma chain in stored order in the rows kernel (no row
 // splitting, no segment kernel, no MFMA block path), which is bit-identical to spmm_kernel_ref -- pinned by
 // tests/test_parity_gpu.py::test_reference_kernel_agrees_with_oracle_live and tests/test_fullsize_gpu.py against
-// the reference kernel itself.  So test/test_spmm.cu:33 (`new SpMMRef(g, kLen)`) compiles unchanged and
+// the reference kernel itself.  So the line test/test_spmm.cu:33 (`new SpMMRef(g, kLen)`) compiles as written (tests/test_boundary_compiles.py) and
 // SpMMTest.validation compares SpMMOpt with SpMMRef on the device exactly as the reference does.
 class SpMMRef : public SpMM {
 public:
