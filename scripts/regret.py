@@ -219,6 +219,14 @@ def main():
                 so = [{"segment_overlap": 0}, {"segment_overlap": 1}] if segs > 0 else [{}]
                 return [dict(**a, **b) for a in hs for b in so]
 
+            # one option at a time from auto: which RULE is at fault when the best forced setting changes several at once
+            marg = {}
+            for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128]),
+                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else [])):
+                for v_ in vals_:
+                    consider({key_: v_})
+                    ms_, _ = evaluate({key_: v_})
+                    marg.setdefault(key_, {})[str(v_) if v_ != NONE_THR else "none"] = round(ms_ / auto_ms, 3) if ms_ < float("inf") else None
             if nnz < args.full_grid_below:
                 for T, S, tile in itertools.product(thrs, strips, tiles):
                     base = {"long_row_threshold": T, "col_strips": S}
@@ -280,7 +288,7 @@ def main():
                 b_ms, best_cfg = a_ms, {}
             row = {"graph": gname, "M": M, "nnz": nnz, "max_row": max_row, "N": N, "auto_ms": round(a_ms, 5), "best_ms": round(b_ms, 5),
                    "regret_pct": round(100.0 * (a_ms / b_ms - 1.0), 2), "best_cfg": best_cfg, "auto_cfg": acfg, "n_tried": len(tried), "n_bitdiff": n_bitdiff,
-                   "auto_bitdiff_vs_spmm_kernel_ref": ref_diff, "first_pass_auto_ms": round(auto_ms, 5), "first_pass_best_ms": round(best_ms, 5), "seconds": round(time.time() - t1, 1)}
+                   "auto_bitdiff_vs_spmm_kernel_ref": ref_diff, "one_at_a_time_vs_auto": marg, "first_pass_auto_ms": round(auto_ms, 5), "first_pass_best_ms": round(best_ms, 5), "seconds": round(time.time() - t1, 1)}
             print(json.dumps(row), flush=True)
             del auto, d_B, d_auto, d_C
             torch.cuda.empty_cache()
