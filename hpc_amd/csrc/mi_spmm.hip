@@ -63,6 +63,9 @@ struct mi_spmm_handle {
     int32_t seg_unsorted;    // segments whose columns do not ascend (-1: not looked at)
     int64_t seg_nnz;         // nonzeros in the whole segments (either plan builder): the strip rule's input, known before any column is read
     int64_t strips_builder;  // 0 (default): strip_segments, one pass; 1: the round-4 pair survey_segments + build_col_strips (cross-check)
+    int64_t fused_step;      // "fused_step": 2 (default) = auto, 0 = never, 1 = whenever the step is eligible: hub rows, segments and short rows as the three
+                             // roles of ONE launch (spmm_kernels.hpp spmm_small_step) instead of 2-3 launches and a side-stream fork / join
+    int32_t last_fused;      // 1: the last run call went through the small-step kernel
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -72,7 +75,8 @@ struct mi_spmm_handle {
     int64_t ldp;
     size_t ws_bytes;
     int32_t max_row_nnz;
-    int32_t local_pct;   // column locality sample (percent); -1 = not measured (host plan builder)
+    int32_t local_pct;   // column locality sample (percent); -1 = not measured
+    int32_t front_pct;   // sampled nonzeros in the first quarter of the columns (percent; uniform columns: 25)
     double preprocess_us;
     double phase_us[5];  // d2h row_ptr + validate, column check, block detection, host segment table, upload
     int32_t last_lpr, last_v, last_launches, last_wide;
@@ -148,6 +152,7 @@ static void free_plan(mi_spmm_handle *h)
     delete h->hub_rows_sorted;
     h->hub_rows_sorted = nullptr;
     h->local_pct = -1;
+    h->front_pct = 25;
     h->ws_bytes = 0;
     h->prepared = false;
 }
@@ -466,8 +471,11 @@ static int plan_col_strips(mi_spmm_handle *h)
     if (V == 4 && lpr > cap) lpr = cap;
     int tile = lpr * V;
     if (tile > h->feat) tile = h->feat;
-    if (h->col_strips == 0 && h->local_pct >= 50) return MI_SPMM_OK;      // columns near the row's own position: neighbouring rows share their B rows through L2 already
-    if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
+    // Columns (almost) all near the row's own position -- banded / mesh matrices: a row sits inside one or two strips, and neighbouring rows share their B rows
+    // through L2 already.  (Round 4 stopped at 50 %: a community order with 58 - 60 % of its nonzeros near the diagonal -- protein- / reddit-community -- still
+    // gathers 40 % from all over a B the caches do not hold, and strips took 33 - 43 % off its steps: profiles/r05_regret.md.)
+    if (h->col_strips == 0 && h->local_pct >= 90) return MI_SPMM_OK;
+    if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz, h->front_pct) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
     if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
     void *d_sv = (char *)h->d_col_bad + 64;            // (the first bytes hold the column-range flag a second plan reads again)
     SegmentSurvey sv;
@@ -478,7 +486,7 @@ static int plan_col_strips(mi_spmm_handle *h)
         if (sv.unsorted) return MI_SPMM_OK;            // a row whose columns do not ascend cannot be cut by column without changing its order
         if ((int64_t)sv.nnz != h->seg_nnz) return MI_SPMM_ESTATE;      // the plan builders' count and the survey's are the same number
     }
-    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz);
+    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz, h->front_pct);
     if (S > h->num_cols) S = h->num_cols;
     if (S > kMaxColStrips) S = kMaxColStrips;
     if (S < 2) return MI_SPMM_OK;
@@ -566,6 +574,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         h->medium_res = po.mthr;
         h->long_thr = po.thr;
         h->local_pct = po.local_pct;
+        h->front_pct = po.front_pct;
         h->seg_nnz = po.seg_nnz;
         {
             const int crc = plan_col_strips(h);
@@ -685,6 +694,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->gpu_preprocess = 1;
     h->block_threads = 256;
     h->split_cols = 1;
+    h->fused_step = 2;      // auto (run_part: short steps only)
     h->col_strips = 0;      // auto (plan.hpp resolve_col_strips)
     h->n_strips = 1;
     h->seg_unsorted = -1;
@@ -766,6 +776,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; }
     else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
+    else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; }
     else if (k == "col_strips_builder") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->strips_builder = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -814,6 +825,8 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "n_col_strips") *value = h->n_strips;
     else if (k == "segments_unsorted") *value = h->seg_unsorted;
     else if (k == "col_strips_builder") *value = h->strips_builder;
+    else if (k == "fused_step") *value = h->fused_step;
+    else if (k == "fused_step_in_force") *value = h->last_fused;
     else if (k == "segment_nnz") *value = h->seg_nnz;
     else if (k == "col_strips_table_hash") {           // FNV-1a over the strip tables (copied back: a test's question, not a step's)
         *value = 0;
@@ -900,6 +913,12 @@ static int preprocess_plan(mi_spmm_handle *h)
     h->max_row_nnz = max_len;
     // (as in the device builder: a block group's list may be as long as the largest candidate of the auto threshold)
     const int32_t detect_max = (int32_t)(h->long_thr > 0 ? h->long_thr : hist_threshold(kHistN - 1));
+    // the column sample the device builder takes inside its own pass (locality: tile width, medium threshold, strips; front-loaded columns: strips)
+    if (h->nnz > 0) {
+        if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
+        const int src = sample_columns_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->nnz, (char *)h->d_col_bad + 64, &h->local_pct, &h->front_pct);
+        if (src != 0) return src;
+    } else h->local_pct = 0;
     if (h->long_thr == 0) {      // auto, exact mode: the same histogram and the same rule as the device builder
         LenHist hist;
         std::memset(&hist, 0, sizeof(hist));
@@ -907,7 +926,7 @@ static int preprocess_plan(mi_spmm_handle *h)
             const int32_t len = ptr[r + 1] - ptr[r];
             for (int i = 0; i < kHistN && len > hist_threshold(i); ++i) { ++hist.cnt[i]; hist.nnz[i] += (unsigned long long)len; }
         }
-        h->long_thr = resolve_hub_threshold(h->nnz, M, h->feat, hist.nnz);
+        h->long_thr = resolve_hub_threshold(h->nnz, M, h->num_cols, h->feat, hist.nnz);
     }
     auto lap = [&](int i, std::chrono::steady_clock::time_point &from) {
         const auto now = std::chrono::steady_clock::now();
@@ -980,10 +999,9 @@ static int preprocess_plan(mi_spmm_handle *h)
     std::vector<Chunk> chunks;
     std::vector<LongRow> longs;
     const int32_t thr = (int32_t)h->long_thr, clen = (int32_t)h->long_chunk;
-    // same auto rule as preprocess_gpu.hip resolve_mthr(): 32 on skewed degree distributions, else 64
-    const int64_t mean_len = M > 0 ? h->nnz / M : 0;
-    const int64_t mrule = h->medium_thr > 0 ? h->medium_thr : ((int64_t)max_len > 8 * (mean_len > 1 ? mean_len : 1) ? 32 : 64);
-    const int32_t mthr = (int32_t)(mrule < h->long_thr ? mrule : h->long_thr);
+    // the same auto rule as the device builder (plan.hpp resolve_medium_threshold)
+    const int32_t mthr = resolve_medium_threshold((int32_t)h->medium_thr, (int32_t)(M > 0 ? h->nnz / M : 0), max_len,
+                                                  (int32_t)(h->long_thr > INT32_MAX ? INT32_MAX : h->long_thr), h->local_pct);
     h->medium_res = mthr;
     int32_t n_slots = 0, n_medium = 0;
     if (max_len > mthr) {
@@ -1171,6 +1189,17 @@ void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 g
     else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s, bt); else launch_block_items_g<1, false, false>(slab, a, grid, s, bt); }
 }
 
+void launch_small_step(int lpr, const SmallStepArgs &a, dim3 grid, hipStream_t s)
+{
+    // segments 16 gathers deep: 114 - 128 VGPRs, inside the hub role's 135 (32 deep would make the whole kernel a 2-waves-per-SIMD kernel)
+    switch (lpr) {
+    case 8: hipLaunchKernelGGL((spmm_small_step<8, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((spmm_small_step<16, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((spmm_small_step<32, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((spmm_small_step<64, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
+    }
+}
+
 template <bool WIDE>
 void launch_hub(int sw, bool excl, const HubArgs &a, dim3 grid, hipStream_t s)
 {
@@ -1180,21 +1209,28 @@ void launch_hub(int sw, bool excl, const HubArgs &a, dim3 grid, hipStream_t s)
     else hipLaunchKernelGGL((spmm_hub<32, WIDE>), grid, dim3(64 * (1 + HubCfg<32>::L)), 0, s, a);
 }
 
-// Column-tile width of the rows / segment kernels when the caller leaves it to us (profiles/r02_wide_n_tiles.txt):
-//   columns near the row's own position (banded / mesh / community structure): whole-wave tiles -- neighbouring rows
-//     share B rows through L2 and a narrower tile only re-reads A (banded N=256: 1.75 ms at 256, 1.88 at 128, 2.15 at 64);
-//   otherwise, N >= 256: 64-column tiles -- the tiles are swept one after the other, so a sweep's B working set is
-//     K x 64 x 4 bytes (256 MiB at K = 2^20: the Infinity Cache's size) instead of 1 GiB (uniform N=1024: 20.3 -> 19.4 ms,
-//     N=256: 5.44 -> 4.79; R-MAT N=512: 10.3 -> 8.3; dense-ish: +6 %);
-//   N < 256 with hub rows (longest row > 64 x mean: R-MAT-like column reuse): 64 as well (R-MAT N=128: 2.09 -> 1.81 ms);
-//   else the whole row (uniform N=128: 2.40 at 128, 2.42 at 64, 2.57 at 32).
+// Column-tile width of the rows / segment kernels when the caller leaves it to us (profiles/r02_wide_n_tiles.txt; round 5: profiles/r05_regret.md):
+//   columns (almost) all near the row's own position (banded / mesh, >= 95 %): whole-wave tiles -- neighbouring rows share B rows through L2 and a
+//     narrower tile only re-reads A (banded N=256: 1.75 ms at 256, 1.88 at 128, 2.15 at 64);
+//   community orders (50 - 94 %: most of a row near the diagonal, the rest all over B): N >= 256 -> 128-column tiles, two rows per wavefront (round 5: six
+//     community-ordered dataset shapes and the plain block model at N = 256: 0.82 - 0.95 of the time with 256; the others neutral); narrower N: the whole row;
+//   otherwise (columns anywhere):
+//     few nonzeros per row (mean < 12: youtube-, am-, arxiv-shaped): the whole row / whole-wave tiles -- a narrower tile multiplies what a ROW costs
+//       (row pointers, its lane group's start, its C store) and such a row has little else (round 5: youtube-shuffled N = 128 / 256 0.83 / 0.79,
+//       arxiv-degree N = 256 0.74, am-degree N = 256 0.82 of the time with 64);
+//     N >= 256: 64-column tiles -- the tiles are swept one after the other, so a sweep's B working set is K x 64 x 4 bytes (256 MiB at K = 2^20: the
+//       Infinity Cache's size) instead of 1 GiB (uniform N=1024: 20.3 -> 19.4 ms, N=256: 5.44 -> 4.79; R-MAT N=512: 10.3 -> 8.3; dense-ish: +6 %);
+//     N < 256 with hub rows (longest row > 64 x mean: R-MAT-like column reuse): 64 as well (R-MAT N=128: 2.09 -> 1.81 ms);
+//     else the whole row (uniform N=128: 2.40 at 128, 2.42 at 64, 2.57 at 32).
 int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
 {
     (void)ldb;
     if (h->tile_cols > 0) return (int)h->tile_cols;
-    if (h->local_pct < 0 || h->local_pct >= 50) return 256;
-    if (N >= 256) return 64;
+    if (h->local_pct < 0 || h->local_pct >= 95) return 256;
+    if (h->local_pct >= 50) return N >= 256 ? 128 : 256;
     const int64_t mean = h->num_v > 0 ? h->nnz / h->num_v : 0;
+    if (mean < 12) return 256;
+    if (N >= 256) return 64;
     if (N >= 128 && (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1)) return 64;
     return 256;
 }
@@ -1261,6 +1297,46 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     const int flags = (remap ? kFlagXcdRemap : 0) | (h->ftz ? kFlagFtz : 0);
     const int pol = (h->nt_store ? kPolNtStore : 0) | (h->nt_stream ? kPolNtStream : 0);
     int launches = 0;
+
+    // ---- small steps: one launch, three roles (spmm_kernels.hpp spmm_small_step) -------------------------------------------------------------
+    // Eligible: the plain case of every role -- 16-byte lanes, narrow addressing, ONE column tile, no column strips, no split rows, no block groups, the
+    // default workgroup size.  auto ("fused_step" = 2): only steps whose bytes take under 0.2 ms at 6 TB/s -- there the launch boundaries and the fork are
+    // a third of the step and the rows role's lower occupancy (3 waves per SIMD, the hub role's footprint) costs nothing; longer steps keep their kernels.
+    {
+        const double step_bytes = (double)h->nnz * (4.0 * full.N + 8.0) + 4.0 * (double)h->num_v * full.N;
+        const bool eligible = vec4 && !wide && col_tiles == 1 && launch_blocks_here && N == full.N && h->n_strips <= 1 && !h->split_long && h->n_blk_groups == 0 &&
+                              bt == kBlockThreads && pol == kPolNtStore && (h->n_long > 0 || h->n_chunks > 0) &&
+                              (int64_t)((full.N + 15) / 16) * h->n_long + (int64_t)h->n_chunks + nblk64 < (int64_t)INT32_MAX;
+        const bool want = h->fused_step == 1 || (h->fused_step == 2 && step_bytes / 6e12 < 200e-6);
+        h->last_fused = 0;
+        if (eligible && want) {
+            SmallStepArgs fa{};
+            const bool hubs_here = h->n_long > 0 && range_has_hub(h, row_begin, row_end);
+            if (hubs_here) {
+                fa.h.rows = h->d_long; fa.h.row_ptr = h->d_ptr; fa.h.col_idx = h->d_idx; fa.h.vals = h->d_val;
+                fa.h.B = full.B; fa.h.C = full.C; fa.h.ldb = ldb; fa.h.ldc = ldc; fa.h.n_hubs = h->n_long; fa.h.N = full.N;
+                fa.h.slices = (full.N + 15) / 16; fa.h.row_lo = row_begin; fa.h.row_hi = row_end; fa.h.flags = h->ftz ? kFlagFtz : 0; fa.h.po = po_full;
+                fa.hub_wgs = fa.h.slices * h->n_long;
+            }
+            if (h->n_chunks > 0) {
+                fa.c.chunks = h->d_chunks; fa.c.col_idx = h->d_idx; fa.c.vals = h->d_val; fa.c.B = d_vin; fa.c.partials = nullptr; fa.c.C = d_vout;
+                fa.c.ldb = ldb; fa.c.ldp = h->ldp; fa.c.ldc = ldc; fa.c.n_chunks = h->n_chunks; fa.c.N = N; fa.c.flags = flags;
+                fa.c.row_lo = row_begin; fa.c.row_hi = row_end; fa.c.po = po;
+                fa.seg_wgs = (h->n_chunks + kBlockThreads / lpr - 1) / (kBlockThreads / lpr);
+            }
+            fa.r.blk_flag = nullptr; fa.r.row_ptr = h->d_ptr; fa.r.col_idx = h->d_idx; fa.r.vals = h->d_val; fa.r.B = d_vin; fa.r.C = d_vout;
+            fa.r.ldb = ldb; fa.r.ldc = ldc; fa.r.row0 = row_begin; fa.r.M = row_end; fa.r.N = N; fa.r.rows_per_block = rpg;
+            fa.r.long_thr = (int32_t)h->medium_res; fa.r.nblk = (int)nblk64; fa.r.flags = flags; fa.r.po = po;
+            const int rows_wgs = h->n_rows_for_rows_kernel > 0 ? (int)nblk64 : 0;       // every row may belong to the first two roles (ddi-shaped graphs)
+            if (fa.hub_wgs + fa.seg_wgs + rows_wgs == 0) { *launches_out += 0; return MI_SPMM_OK; }
+            dim3 fgrid((unsigned)(fa.hub_wgs + fa.seg_wgs + rows_wgs));
+            launch_small_step(lpr, fa, fgrid, s);
+            h->last_fused = 1;
+            if (record) { h->last_wide = 0; h->last_lpr = lpr; h->last_v = V; }
+            *launches_out += 1;
+            return (int)hipGetLastError();
+        }
+    }
 
     // segment, hub, block and reduce kernels walk their whole tables and keep the rows of this call's range.
     // The hub kernel goes first (its longest row is the step's longest dependent chain) and, like the block kernel,

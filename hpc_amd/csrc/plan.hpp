@@ -13,13 +13,16 @@ namespace mi {
 // ---- auto hub threshold of the default (exact-order) mode ------------------------------------------------------
 // Two kernels take rows in stored order: the segment kernel (one lane group per row, 32 gathers in flight: 47 ns per
 // nonzero of ONE row on an idle chip, 140-430 ns beside a rows kernel that saturates the fabric; but thousands of rows at
-// once, i.e. full memory throughput) and the hub kernel (4.1 ns per nonzero of one row, about half the segment kernel's
+// once, i.e. full memory throughput) and the hub kernel (3.2 ns per nonzero of one row, about half the segment kernel's
 // throughput).  So: a row becomes a hub when, as a segment on its side stream, it could no longer hide behind the rest of
 // the step -- L x (100 + 1.3 N) ns > half the step's estimated time (gather-model bytes at 6 TB/s) -- unless the rows above that
 // length hold more than a quarter of all nonzeros: then the hub kernel would carry the step at its lower throughput, and the
 // threshold moves up until they do not (ddi-shaped graphs: every row is long) -- as long as a segment of that length still fits
 // inside the step (below).  Candidates 256 .. 8192, powers of two.
 // Measured against fixed thresholds on eight graph shapes x three widths: profiles/r03_hub_thresholds.txt.
+// Round 5 (profiles/r05_regret.md, ddi-community kLen 128 / 256: regret 16 / 33 %): when B is L2-RESIDENT (4 K N <= 6 MiB: a gather is an L2 hit, not a
+// trip to the fabric) the step runs at the L2's gather rate (18 TB/s) and a segment's nonzero costs ~30 ns beside the others, ~16 ns alone -- the
+// constants above price such a step 3x too long and its segments 5x too slow, and rows went to the hub kernel that were faster as segments.
 // The histogram comes from the same pass over row_ptr that finds the longest row; both plan builders use this function.
 constexpr int kHistN = 6;
 __host__ __device__ inline int32_t hist_threshold(int i) { return 256 << i; }
@@ -27,13 +30,16 @@ struct LenHist {
     uint32_t cnt[kHistN];             // rows longer than hist_threshold(i)
     unsigned long long nnz[kHistN];   // ... and the nonzeros they hold
 };
-__host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M, int32_t N, const unsigned long long *nnz_above)
+__host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M, int32_t K, int32_t N, const unsigned long long *nnz_above)
 {
     const double bytes = (double)nnz * (4.0 * N + 8.0) + 4.0 * (double)M * N;
+    const bool resident = 4.0 * (double)K * (double)N <= 6.0 * 1048576.0;
+    const double step = bytes / (resident ? 18e12 : 6e12);
     // a segment's cost per nonzero beside a saturating rows kernel grows with the bytes per gather: ~140 ns at N = 32, ~270 at 128,
     // ~430 at 256 (am-shaped N = 256: spmm_chunks 0.88 ms for 2 048-nonzero rows, profiles/r03b_am_kernel_stats.csv)
-    const double seg_ns = 100.0 + 1.3 * (double)(N < 256 ? N : 256);
-    const double t = 0.5 * (bytes / 6e12) / (seg_ns * 1e-9);
+    const double seg_ns = resident ? 30.0 : 100.0 + 1.3 * (double)(N < 256 ? N : 256);
+    const double idle_ns = resident ? 16.0 : 47.0;
+    const double t = 0.5 * step / (seg_ns * 1e-9);
     int i = 0;
     while (i + 1 < kHistN && (double)hist_threshold(i + 1) <= t) ++i;
     const int i_lat = i;
@@ -41,8 +47,23 @@ __host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M,
     // ... but not so far up that ONE segment of that length, even on an idle chip (47 ns per nonzero), outlasts the whole step's
     // estimate: a small matrix of long rows (ddi-shaped, N = 32: 4 267 rows, 44 us of bytes, an 1 772-nonzero row = 83 us as a
     // segment) is then latency-bound whatever the hub kernel's throughput, and the shorter chain wins (69 -> 42 us)
-    while (i > i_lat && (double)hist_threshold(i) * 47e-9 > bytes / 6e12) --i;
+    while (i > i_lat && (double)hist_threshold(i) * idle_ns * 1e-9 > step) --i;
     return hist_threshold(i);
+}
+
+// ---- auto medium threshold (rows above it leave the rows kernel for the length-sorted segment kernel) -------------------------------------
+// 64 when the degrees are even (the rows kernel's lane groups finish together anyway), 32 when the longest row is more than 8x the mean -- skewed graphs,
+// where neighbours in a wave differ widely (profiles/r01_medium_threshold.txt).  Round 5: that was measured on uniformly random columns only.  Where the
+// columns are LOCAL (community / mesh order: >= 50 % of the sampled nonzeros near their row's own position) neighbouring rows gather the same B rows and
+// meet in one L2 -- in the rows kernel, which walks the rows in order; the segment table is sorted by LENGTH, which scatters exactly those neighbours over
+// the chip.  There the rows kernel keeps rows up to 256 nonzeros (profiles/r05_regret.md: ppa- / products- / yelp- / citation-community 64 -> 0.85,
+// 128 -> 0.72 - 0.77 of the time at 32; non-local orders of the same graphs: 64 and 128 LOSE 16 - 38 %).
+__host__ __device__ inline int32_t resolve_medium_threshold(int32_t mthr_user, int32_t mean_len, int32_t max_len, int32_t thr, int32_t local_pct)
+{
+    int32_t m = mthr_user > 0 ? mthr_user
+              : local_pct >= 50 ? 256
+              : ((int64_t)max_len > 8 * (int64_t)(mean_len > 1 ? mean_len : 1) ? 32 : 64);
+    return m < thr ? m : thr;
 }
 
 struct PlanOut {
@@ -53,7 +74,8 @@ struct PlanOut {
     int32_t max_len = 0;
     int32_t mthr = 0;               // resolved medium threshold (the rows kernel skips rows above it)
     int32_t thr = 0;                // resolved hub threshold (the caller's value, or the auto rule above)
-    int32_t local_pct = 0;          // sampled nonzeros within a window of their row's own position, percent (column-tile rule)
+    int32_t local_pct = 0;          // sampled nonzeros within a window of their row's own position, percent (column-tile, medium-threshold and strip rules)
+    int32_t front_pct = 0;          // sampled nonzeros whose column lies in the first quarter of the columns, percent (uniform: 25; hubs-first vertex orders: 50+)
     int64_t seg_nnz = 0;            // nonzeros in the whole (exact) segments: lets the column-strip rule pick S before any column is read
 };
 
@@ -72,6 +94,8 @@ void scratch_release(Scratch *s);
 
 // thr: hub threshold, 0 = auto (exact mode only; resolved on the device from the row-length histogram, returned in PlanOut::thr).
 // N: dense width (the auto rule's byte estimate).
+// the column sample on its own (the host plan builder has no device pass of its own over the rows): synchronises
+int sample_columns_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, void *d_scratch256, int32_t *local_pct, int32_t *front_pct);
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int32_t N, int64_t nnz,
                    const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, int32_t split,
                    Scratch *sa, Scratch *sb, PlanOut *out);
@@ -96,7 +120,11 @@ int strip_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col
 int survey_segments(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, void *d_scratch256, SegmentSurvey *out);   // synchronises (one 16-byte copy)
 int build_col_strips(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_col_idx, int32_t K, int32_t S, Chunk *d_strips);   // asynchronous on the null stream
 // the rule: how many strips for this plan (1 = none)
-inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz, int32_t n_segments, int64_t nnz)
+// front_pct (round 5): share of sampled nonzeros in the first quarter of the columns.  A vertex order that puts the hubs first (un-permuted R-MAT, crawl
+// orders) puts the hot rows of B into the FIRST strip whatever its width; strips then cannot reach L2 size by the rule above (sub-segments would get too
+// short) and yet four wide ones pay: the first launch gathers the hot rows with nothing cold evicting them, the others stream (rmat20-unpermuted kLen 32 /
+// 128 / 256: 0.88 / 0.95 / 0.87 of the time without, profiles/r05_regret.md).
+inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz, int32_t n_segments, int64_t nnz, int32_t front_pct = 25)
 {
     // Measured on protein- and reddit-shaped graphs at N = 32 / 128 / 256, strip counts interleaved in one process (profiles/r04_col_strips.txt, sections 2
     // and 9): the best strip holds 4 - 6 MiB of B per column tile (one to one and a half XCD L2s; smaller strips pay more launches and shorter sub-segments
@@ -108,6 +136,8 @@ inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz,
     const int64_t by_len = seg_nnz / n_segments / 20;                   // sub-segments of >= 20 nonzeros on average
     if (s > by_len) s = by_len;
     if (s > 32) s = 32;
+    const bool front_loaded = front_pct >= 50 && by_len >= 4;           // (sub-segments of >= 80 nonzeros on average with four strips)
+    if (front_loaded && (s < 2 || b_bytes / (double)s > 8.0 * 1048576.0)) return 4;
     if (s < 2) return 1;
     if (b_bytes / (double)s > 16.0 * 1048576.0) return 1;               // B far beyond the caches: strips that large buy nothing
     return (int32_t)s;

@@ -25,6 +25,7 @@ struct PlanStats {
     int32_t n_groups_selected;
     int32_t mthr;      // resolved medium threshold (auto rule below, or the caller's value), already capped by thr
     int32_t near, sampled;   // column locality sample: nonzeros of sampled rows whose column lies near the row's own position
+    int32_t front, pad2;     // ... and those whose column lies in the first quarter of the columns (hubs-first vertex orders)
     int32_t thr;       // resolved hub threshold (the caller's value or resolve_hub_threshold)
     int32_t pad;
     LenHist hist;      // rows above 256 .. 8192 nonzeros and what they hold (the auto hub threshold reads it)
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *
                                                                 int32_t M, int32_t K, int64_t nnz, int32_t n_samples, int32_t window, PlanStats *stats)
 {
     const int i = (int)(blockIdx.x * (unsigned)kBlockThreads + threadIdx.x);
-    int near = 0, tot = 0;
+    int near = 0, tot = 0, front = 0;
     if (i < n_samples) {
         const int r = (int)((int64_t)i * M / n_samples);
         const int beg = row_ptr[r], end = row_ptr[r + 1];
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *
             for (int k = beg; k < end; ++k) {
                 const int64_t d = (int64_t)col_idx[k] - home;
                 near += (d <= window && d >= -(int64_t)window) ? 1 : 0;
+                front += col_idx[k] < K / 4 ? 1 : 0;
             }
             tot = end - beg;
         }
@@ -59,10 +61,12 @@ __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *
     for (int off = 32; off > 0; off >>= 1) {
         near += __shfl_down(near, off, 64);
         tot += __shfl_down(tot, off, 64);
+        front += __shfl_down(front, off, 64);
     }
     if ((threadIdx.x & 63) == 0 && tot > 0) {
         atomicAdd(&stats->near, near);
         atomicAdd(&stats->sampled, tot);
+        atomicAdd(&stats->front, front);
     }
 }
 
@@ -91,19 +95,10 @@ __global__ __launch_bounds__(kBlockThreads) void row_len_max(const int32_t *__re
         atomicMax(&stats->max_len, m);
 }
 
-// Rows above the medium threshold leave the rows kernel for the length-sorted segment kernel.  auto: 64 when
-// the degrees are even (the rows kernel's lane groups finish together anyway), 32 when the longest row is more
-// than 8x the mean -- skewed graphs, where neighbours in a wave differ widely (profiles/r01_medium_threshold.txt).
-__device__ __forceinline__ int resolve_mthr(int mthr_user, int mean_len, int max_len, int thr)
-{
-    int m = mthr_user > 0 ? mthr_user : ((int64_t)max_len > 8 * (int64_t)(mean_len > 1 ? mean_len : 1) ? 32 : 64);
-    return m < thr ? m : thr;
-}
-
 __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__restrict__ row_ptr, int32_t M,
                                                               const uint8_t *__restrict__ blk_flag, int32_t mthr_user,
                                                               int32_t mean_len, int32_t thr_user, int32_t clen, int32_t split,
-                                                              int64_t nnz, int32_t N,
+                                                              int64_t nnz, int32_t K, int32_t N,
                                                               int32_t *__restrict__ seg_cnt,
                                                               int32_t *__restrict__ slot_cnt,
                                                               int32_t *__restrict__ long_cnt, PlanStats *stats)
@@ -112,8 +107,9 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
     int len = 0;
     unsigned bad = 0;
     // max_len and the histogram are complete (previous kernel); every thread resolves the same two thresholds
-    const int thr = thr_user > 0 ? thr_user : resolve_hub_threshold(nnz, M, N, stats->hist.nnz);
-    const int mthr = resolve_mthr(mthr_user, mean_len, stats->max_len, thr);
+    const int thr = thr_user > 0 ? thr_user : resolve_hub_threshold(nnz, M, K, N, stats->hist.nnz);
+    const int local_pct = stats->sampled > 0 ? (int)(100.0 * stats->near / stats->sampled) : 0;      // (sample_locality ran before this kernel, same stream)
+    const int mthr = resolve_medium_threshold(mthr_user, mean_len, stats->max_len, thr, local_pct);
     if (r < M) {
         const int beg = row_ptr[r], end = row_ptr[r + 1];
         len = end - beg;
@@ -238,6 +234,28 @@ void scratch_release(Scratch *s)
 
 #define PLAN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (e_ == hipErrorOutOfMemory) ? MI_SPMM_ENOMEM : (int)e_; } while (0)
 
+int sample_columns_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, void *d_scratch256, int32_t *local_pct, int32_t *front_pct)
+{
+    static_assert(sizeof(PlanStats) <= 192, "the caller's 256-byte scratch holds the statistics behind its first 64 bytes");
+    *local_pct = 0;
+    *front_pct = 0;
+    if (M <= 0 || K <= 0 || nnz <= 0) return 0;
+    PlanStats *stats = (PlanStats *)d_scratch256;
+    hipLaunchKernelGGL(init_plan_stats, dim3(1), dim3(64), 0, 0, stats);
+    const int n_samples = M < 8192 ? M : 8192;
+    const int window = K / 64 > 4096 ? K / 64 : 4096;
+    hipLaunchKernelGGL(sample_locality, dim3((unsigned)((n_samples + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
+                       d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
+    PLAN_TRY(hipGetLastError());
+    PlanStats host;
+    PLAN_TRY(hipMemcpy(&host, stats, sizeof(PlanStats), hipMemcpyDeviceToHost));
+    if (host.sampled > 0) {
+        *local_pct = (int32_t)(100.0 * host.near / host.sampled);
+        *front_pct = (int32_t)(100.0 * host.front / host.sampled);
+    }
+    return 0;
+}
+
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int32_t N, int64_t nnz,
                    const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr_user, int32_t clen, int32_t split,
                    Scratch *sa, Scratch *sb, PlanOut *out)
@@ -284,7 +302,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                            d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
     }
     hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
-                       (int32_t)(nnz / M), thr_user, clen, split, nnz, N, seg_cnt, slot_cnt, long_cnt, stats);
+                       (int32_t)(nnz / M), thr_user, clen, split, nnz, K, N, seg_cnt, slot_cnt, long_cnt, stats);
     PLAN_TRY(hipGetLastError());
     size_t t = tb;
     PLAN_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, t, seg_cnt, seg_off, (int)n1));
@@ -319,6 +337,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     out->thr = host.st.thr;
     const int32_t thr = host.st.thr;
     out->local_pct = host.st.sampled > 0 ? (int32_t)(100.0 * host.st.near / host.st.sampled) : 0;
+    out->front_pct = host.st.sampled > 0 ? (int32_t)(100.0 * host.st.front / host.st.sampled) : 0;
     out->n_chunks = host.n_chunks;
     out->n_slots = host.n_slots;
     out->n_long = host.n_long;

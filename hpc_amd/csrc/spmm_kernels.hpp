@@ -274,8 +274,9 @@ segment_chain_v2(const int32_t *__restrict__ col_idx, const float *__restrict__ 
     return acc;
 }
 
+// (the body is a device function of (arguments, block coordinates) so that the small-step kernel at the end of this file can run it as one of its roles)
 template <int V, int LPR, int UNROLL, bool WIDE, int POL, int BT>
-__global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
+__device__ __forceinline__ void rows_v2_body(const RowsArgs &a, const int bx, const int by)
 {
     constexpr int GPB = BT / LPR;
     constexpr int PV = (LPR >= 32) ? 1 : (32 / LPR);
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
     const int tid = threadIdx.x;
     const int g = tid / LPR;
     const int lig = tid % LPR;
-    const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(blockIdx.x, a.nblk) : (int)blockIdx.x;
-    const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
+    const int vb = (a.flags & kFlagXcdRemap) ? xcd_remap(bx, a.nblk) : bx;
+    const int col_raw = (by * LPR + lig) * V;
     const bool col_ok = col_raw < a.N;
     const int col = min(col_raw, a.N - V);   // see spmm_rows: tail lane shifted back, lanes past N store nothing
     const uint32_t ldb_bytes = (uint32_t)a.ldb * 4u, col_bytes = (uint32_t)col * 4u;
@@ -353,6 +354,12 @@ __global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
     }
 }
 
+template <int V, int LPR, int UNROLL, bool WIDE, int POL, int BT>
+__global__ __launch_bounds__(BT) void spmm_rows_v2(RowsArgs a)
+{
+    rows_v2_body<V, LPR, UNROLL, WIDE, POL, BT>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // ---- chunks kernel: long rows, one lane group per chunk ----------------------
 struct ChunkArgs {
     const Chunk *chunks;
@@ -372,16 +379,16 @@ struct ChunkArgs {
 };
 
 template <int V, int LPR, int UNROLL, bool WIDE>
-__global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
+__device__ __forceinline__ void chunks_body(const ChunkArgs &a, const int bx, const int by)
 {
     constexpr int GPB = kBlockThreads / LPR;
     apply_ftz(a.flags);
     const int tid = threadIdx.x;
     const int g = tid / LPR;
     const int lig = tid % LPR;
-    const int ch = (int)blockIdx.x * GPB + g;
+    const int ch = bx * GPB + g;
     if (ch >= a.n_chunks) return;
-    const int col_raw = ((int)blockIdx.y * LPR + lig) * V;
+    const int col_raw = (by * LPR + lig) * V;
     const bool col_ok = col_raw < a.N;
     const int col = min(col_raw, a.N - V);   // see spmm_rows: tail lane shifted back, lanes past N store nothing
     Chunk c = a.chunks[ch];
@@ -406,6 +413,12 @@ __global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
         else if (a.flags & kFlagStripCarry) Vec<V>::template store<false>(a.C + coff, acc);   // a later strip reads it back: plain store, local C only
         else store_c_all<V, true>(a.C, a.po, coff, acc);
     }
+}
+
+template <int V, int LPR, int UNROLL, bool WIDE>
+__global__ __launch_bounds__(kBlockThreads) void spmm_chunks(ChunkArgs a)
+{
+    chunks_body<V, LPR, UNROLL, WIDE>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---- reduce kernel: C[row] = ((p0 + p1) + p2) + ...  in chunk order ----------
@@ -516,7 +529,7 @@ __device__ __forceinline__ void hub_flag_store(int *p, int v)
 }
 
 template <int SW, bool WIDE, bool EXCL = false>
-__global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
+__device__ __forceinline__ void hub_body(const HubArgs &a, const int bx)
 {
     typedef HubCfg<SW> K;
     constexpr int L = K::L, U = K::U, LPS = K::LPS, NG = K::NG, NBK = K::NBK, CS = K::CS, NB = K::NB;
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
     if (EXCL) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int hub = (int)blockIdx.x / a.slices, slice = (int)blockIdx.x - hub * a.slices;
+    const int hub = bx / a.slices, slice = bx - hub * a.slices;
     const int row = __builtin_amdgcn_readfirstlane(a.rows[hub].row);
     if (row < a.row_lo || row >= a.row_hi) return;        // workgroup-uniform
     const int beg = __builtin_amdgcn_readfirstlane(a.row_ptr[row]);
@@ -679,6 +692,38 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
         const int s = s0 + u * L;
         if (s < n_st) publish(R[u], s);
     }
+}
+
+template <int SW, bool WIDE, bool EXCL = false>
+__global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
+{
+    hub_body<SW, WIDE, EXCL>(a, (int)blockIdx.x);
+}
+
+// ---- small steps: ONE launch whose workgroups take their role from blockIdx (round 5) ----------------------------------------------
+// A step of tens of microseconds (arxiv-, collab-, ddi-shaped graphs at kLen 32: 40 - 70 us) is two or three launches -- hub rows, segments, short
+// rows -- plus, where the longest hub is worth overlapping, a side-stream fork and join of ~20 us: each launch boundary drains the chip and each fork waits for
+// an event to cross queues, and on such steps that IS a third of the time (profiles/r05_report_table.md: time / floor).  Here the three kernels are the three
+// roles of one grid: workgroups [0, hub_wgs) are hub (row, slice) workgroups -- first in the grid, so the longest dependent chain of the step starts first
+// (the hub table is longest-first) --, [hub_wgs, hub_wgs + seg_wgs) take segments (longest first as well), the rest short rows.  No fork, no join, no
+// stream test, one ramp.  Same device functions, same arguments, same arithmetic: same bits.
+// Footprint (make asm, -Rpass-analysis=kernel-resource-usage): the kernel's registers and LDS are the largest role's -- the hub role with 16-column slices
+// (135 VGPRs, 27.7 KB of LDS: 3 waves per SIMD) -- so the rows role runs at 3 waves per SIMD instead of 5 - 8: acceptable only where the step is short and
+// latency-bound anyway, which is the host's rule for using this kernel (mi_spmm.hip: estimated step < 0.2 ms, one column tile, no strips, no blocks).
+struct SmallStepArgs {
+    HubArgs h;
+    ChunkArgs c;
+    RowsArgs r;
+    int32_t hub_wgs, seg_wgs;       // workgroups of the first two roles (0: role absent)
+};
+
+template <int LPR, int SEG_UNROLL>
+__global__ __launch_bounds__(kBlockThreads) void spmm_small_step(SmallStepArgs a)
+{
+    const int b = (int)blockIdx.x;
+    if (b < a.hub_wgs) hub_body<16, false, false>(a.h, b);
+    else if (b < a.hub_wgs + a.seg_wgs) chunks_body<4, LPR, SEG_UNROLL, false>(a.c, b - a.hub_wgs, 0);
+    else rows_v2_body<4, LPR, 8, false, kPolNtStore, kBlockThreads>(a.r, b - a.hub_wgs - a.seg_wgs, 0);
 }
 
 // ---- block path: 16-row groups with one shared column list -----------------------

@@ -64,10 +64,25 @@ def graph_list(quick):
         "protein-community": ds("protein"), "protein-shuffled": ds("protein", order="shuffled"), "protein-unsorted": ds("protein", sort_cols=False),
         "reddit-community": ds("reddit.dgl"), "reddit-degree": ds("reddit.dgl", order="degree"),
         "products-community": ds("products"),
+        # every column within +-2048 of the row (mesh-like): 300-700 nonzeros per row -> segments whose rows sit inside one or two column strips
+        "banded-long-rows": lambda dev: _banded_long_rows(dev),
+        "banded-deg32": lambda dev: tuple(__import__("torch").from_numpy(a).to(dev) for a in synth.csr_banded(1 << 20)),
     }
     if quick:
         g = {k: g[k] for k in ("arxiv-community", "ddi-community", "youtube-community", "protein-community")}
     return g
+
+
+def _banded_long_rows(dev, M=1 << 17, width=2048, lo=300, hi=700):
+    import torch
+    from hpc_amd import synth
+
+    deg = torch.from_numpy(synth._rng(7, 7).integers(lo, hi + 1, size=M)).to(dev)
+    rows = torch.repeat_interleave(torch.arange(M, device=dev), deg)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    off = torch.randint(-width, width + 1, (rows.numel(),), generator=gen, device=dev)
+    return synth._csr_from_pairs_device(rows, (rows + off).clamp_(0, M - 1), M, M)
 
 
 class Timer:
@@ -221,7 +236,7 @@ def main():
 
             # one option at a time from auto: which RULE is at fault when the best forced setting changes several at once
             marg = {}
-            for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128]),
+            for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128, 256, 512]),
                                 ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else [])):
                 for v_ in vals_:
                     consider({key_: v_})
@@ -251,7 +266,7 @@ def main():
                     for extra in hub_dims(cur):
                         consider(dict(cur, **extra))
                     cur = dict(best[0])
-                    for m in (32, 64, 128):
+                    for m in (32, 64, 128, 256, 512):
                         consider(dict(cur, medium_row_threshold=m))
                     cur = dict(best[0])
                     for ho in (0, 2):
@@ -265,7 +280,7 @@ def main():
             # the medium threshold and hub_overlap for the small graphs too (coordinate sweeps at the best point)
             if nnz < args.full_grid_below:
                 cur = dict(best[0])
-                for m in (32, 64, 128):
+                for m in (32, 64, 128, 256, 512):
                     consider(dict(cur, medium_row_threshold=m))
                 cur = dict(best[0])
                 for ho in (0, 2):
