@@ -179,7 +179,8 @@ def main():
             acfg = {"thr": auto.get_option("long_row_threshold"), "S": auto.get_option("n_col_strips"), "tile": auto.get_option("lanes_per_row") * 4,
                     "mthr": auto.get_option("medium_row_threshold"), "hubs": auto.get_option("n_hub_rows"), "segments": auto.get_option("n_chunks"),
                     "seg_nnz_pct": round(100.0 * auto.get_option("segment_nnz") / max(1, nnz), 1), "locality_pct": auto.get_option("column_locality_pct"),
-                    "unsorted": auto.get_option("segments_unsorted"), "launches": auto.get_option("n_launches"), "preprocess_us": auto.get_option("preprocess_us")}
+                    "unsorted": auto.get_option("segments_unsorted"), "launches": auto.get_option("n_launches"), "preprocess_us": auto.get_option("preprocess_us"),
+                    "fused": auto.get_option("fused_step_in_force"), "front_pct": None}
             ref_diff = None
             if not args.no_ref and oracle.ref_available():
                 d_R = torch.zeros((M, N), device=dev)
@@ -237,7 +238,7 @@ def main():
             # one option at a time from auto: which RULE is at fault when the best forced setting changes several at once
             marg = {}
             for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128, 256, 512]),
-                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else [])):
+                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else []), ("fused_step", [0, 1])):
                 for v_ in vals_:
                     consider({key_: v_})
                     ms_, _ = evaluate({key_: v_})
@@ -247,10 +248,12 @@ def main():
                     base = {"long_row_threshold": T, "col_strips": S}
                     if tile:
                         base["tile_cols"] = tile
-                    consider(base)
-                    for extra in hub_dims(base):
+                    consider(base)                       # (fused_step auto: the small-step kernel where eligible)
+                    sep = dict(base, fused_step=0)       # the separate kernels, with the options that only they have
+                    consider(sep)
+                    for extra in hub_dims(sep):
                         if extra:
-                            consider(dict(base, **extra))
+                            consider(dict(sep, **extra))
             else:
                 for T, S in itertools.product(thrs, strips):
                     consider({"long_row_threshold": T, "col_strips": S})
@@ -271,6 +274,9 @@ def main():
                     cur = dict(best[0])
                     for ho in (0, 2):
                         consider(dict(cur, hub_overlap=ho))
+                    cur = dict(best[0])
+                    for fs in (0, 1):
+                        consider(dict(cur, fused_step=fs))
                     cur = dict(best[0])
                     for T in thrs:
                         consider(dict(cur, long_row_threshold=T))
