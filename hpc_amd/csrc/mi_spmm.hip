@@ -845,6 +845,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "num_cols") *value = h->num_cols;
     else if (k == "max_row_nnz") *value = h->max_row_nnz;
     else if (k == "column_locality_pct") *value = h->local_pct;
+    else if (k == "column_front_pct") *value = h->front_pct;
     else if (k == "n_launches") *value = h->last_launches;
     else if (k == "lanes_per_row") *value = h->last_lpr;
     else if (k == "vector_width") *value = h->last_v;
@@ -1358,7 +1359,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         ha.flags = h->ftz ? kFlagFtz : 0;
         ha.po = po_full;
         // Slice width, when the caller leaves it to us: 32 columns per chain wave -- unless the longest row's chain alone
-        // (4.1 ns per nonzero) is more than half of what the whole step's bytes take at 6 TB/s, i.e. that one chain is the
+        // (3.3 ns per nonzero) is more than half of what the whole step's bytes take at 6 TB/s, i.e. that one chain is the
         // step: then 16, whose loaders put half as much through the LDS the chain wave reads from (am-shaped, N = 128:
         // 0.84 -> 0.72 ms; where the hub rows are many rather than one long, 32 is faster: R-MAT N = 32 0.47 vs 0.56;
         // profiles/r03_hub_experiments.txt)

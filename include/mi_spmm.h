@@ -120,12 +120,15 @@ const char *mi_spmm_strerror(int code);
 
 /* Tuning / introspection.  Keys (all int64):
  *   "medium_row_threshold" rows longer than this run as ONE exact segment in the segment kernel (0 = auto:
- *                         64, or 32 when the longest row exceeds 8x the mean degree; get returns the
- *                         resolved value after preprocess).  Scheduling only: results do not depend on it
+ *                         64, or 32 when the longest row exceeds 8x the mean degree -- 256 where the columns are local
+ *                         (>= 50 % of a row sample near the row's own position: the rows kernel keeps neighbours together,
+ *                         the length-sorted segment table scatters them; plan.hpp resolve_medium_threshold); get returns
+ *                         the resolved value after preprocess).  Scheduling only: results do not depend on it
  *   "long_row_threshold"  rows with more nonzeros are HUBS: they leave the segment kernel for the hub kernel (stored order:
- *                         loader waves + one chain wave per 32-column slice, 4.1 ns per nonzero of a row instead of 47).
- *                         0 = auto: a power of two in 256 .. 8192 from the row-length histogram (hpc_amd/csrc/plan.hpp
- *                         resolve_hub_threshold); get returns the resolved value after preprocess.  Scheduling only in
+ *                         loader waves + one chain wave per 32-column slice, 3.2 ns per nonzero of a row instead of 47).
+ *                         0 = auto: a power of two in 256 .. 8192 from the row-length histogram, priced at the L2's rates
+ *                         when B is L2-resident (hpc_amd/csrc/plan.hpp resolve_hub_threshold); get returns the resolved
+ *                         value after preprocess.  Scheduling only in
  *                         the default mode: results do not depend on it
  *   "split_long_rows"     0 (default): hubs keep their stored order.  1: hubs are cut into pieces of "long_row_chunk"
  *                         nonzeros whose partial sums are added left to right (deterministic, not the reference's order;
@@ -150,6 +153,12 @@ const char *mi_spmm_strerror(int code);
  *                         entry); bit-identical to spmm_kernel_ref compiled with the matching switch (hipcc -fgpu-flush-denormals-to-zero)
  *                         on data full of subnormals.  The f32 MFMA block path is not used with it.  On data that holds no subnormals and
  *                         produces none (the reference's N(0, 0.1) inputs) the two settings give the same bits.
+ *   "fused_step"          2 (default, auto) / 0 / 1: hub rows, segments and short rows as the three ROLES OF ONE LAUNCH (spmm_small_step: workgroups
+ *                         take their role from blockIdx, hub slices first so that the step's longest chain starts first) instead of two or three
+ *                         launches plus a side-stream fork and join.  Eligible: one column tile (N <= 256), no column strips, no split rows, no
+ *                         block groups, default cache policy.  auto: only steps whose bytes take under 0.2 ms at 6 TB/s (there the launch
+ *                         boundaries are a third of the step; the rows role runs at the hub role's footprint, 3 waves per SIMD).  1: whenever
+ *                         eligible.  Same device functions, same arithmetic: same bits.  Read-only "fused_step_in_force": the last run used it
  *   "use_graph"           0 (default) / 1: the step's launch set (2-4 kernels plus the side streams' fork and join) is captured once
  *                         into a HIP graph on a handle-owned stream and run() replays it with ONE hipGraphLaunch on the caller's
  *                         stream -- for steps of tens of microseconds (small graphs) the launches are the step.  preprocess captures
@@ -170,7 +179,11 @@ const char *mi_spmm_strerror(int code);
  *                         gathers out of K / S rows of B -- an L2-sized piece when B is a few tens of MiB (graphs of long rows over few
  *                         columns: 1.2 - 1.6 x).  0 = auto (hpc_amd/csrc/plan.hpp resolve_col_strips: about 5 MiB of B per strip and column
  *                         tile, sub-segments of >= 20 nonzeros, at most 32 strips), 1 = off, 2 .. 64 = that many.  Needs ascending columns in
- *                         every segment (checked by preprocess; otherwise no strips).  Scheduling only: results do not depend on it
+ *                         every segment (checked by preprocess; otherwise no strips).  Scheduling only: results do not depend on it.
+ *                         auto also: none where >= 90 % of a row sample lies near the row's own position (banded / mesh); four wide strips where
+ *                         the columns are front-loaded (hubs-first vertex orders: >= 50 % of the sample in the first quarter of the columns)
+ *   "col_strips_builder"  0 (default): the tables are written in the same single pass over the segments' columns that checks their order
+ *                         (strip_segments); 1: round 4's survey + S binary searches per segment (kept as the cross-check: same tables)
  *   "xcd_remap"           0/1: contiguous row ranges per XCD; -1 = auto
  *   "gpu_preprocess"      1 (default): segment table built on the device; 0: reference-style host loop
  *   "kernel"              2: pipelined items (spmm_rows_v2).  1 named the first-generation kernel: MI_SPMM_EUNSUPPORTED
@@ -188,7 +201,9 @@ const char *mi_spmm_strerror(int code);
  *   "n_launches", "lanes_per_row", "preprocess_us", "feat", "num_v", "num_cols", "max_row_nnz",
  *   "n_block_groups", "n_block_pieces", "n_block_items", "n_block_shared_items", "n_block_passes",
  *   "column_locality_pct" (share of sampled nonzeros near their row's own position; behind the "tile_cols" auto rule),
- *   "n_col_strips" (strips in force, 1 = none), "segments_unsorted" (segments whose columns do not ascend; -1 = not looked at) */
+ *   "column_front_pct" (share of the sample in the first quarter of the columns; uniform: 25),
+ *   "n_col_strips" (strips in force, 1 = none), "segments_unsorted" (segments whose columns do not ascend; -1 = not looked at),
+ *   "segment_nnz" (nonzeros in the whole segments), "col_strips_table_hash" (FNV-1a of the strip tables, copied back: tests) */
 int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t value);
 int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value);
 

@@ -180,7 +180,7 @@ def main():
                     "mthr": auto.get_option("medium_row_threshold"), "hubs": auto.get_option("n_hub_rows"), "segments": auto.get_option("n_chunks"),
                     "seg_nnz_pct": round(100.0 * auto.get_option("segment_nnz") / max(1, nnz), 1), "locality_pct": auto.get_option("column_locality_pct"),
                     "unsorted": auto.get_option("segments_unsorted"), "launches": auto.get_option("n_launches"), "preprocess_us": auto.get_option("preprocess_us"),
-                    "fused": auto.get_option("fused_step_in_force"), "front_pct": None}
+                    "fused": auto.get_option("fused_step_in_force"), "front_pct": auto.get_option("column_front_pct")}
             ref_diff = None
             if not args.no_ref and oracle.ref_available():
                 d_R = torch.zeros((M, N), device=dev)
