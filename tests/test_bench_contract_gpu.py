@@ -53,6 +53,9 @@ def test_single_gpu_line():
             assert key in ro, (k, key)
         if ro["bound"] == "chain":       # lower is better: floor / achieved
             assert abs(ro["frac"] - ro["floor_cycles"] / ro["cycles_per_nonzero"]) < 1e-3 and ro["achieved"] == ro["cycles_per_nonzero"]
+        elif ro["frac"] is None:         # only the counter-less cache-resident form may decline to claim a fraction (this down-sized B is 4 MiB)
+            assert ro["bound"] == "l2_gather" and ro["achieved"] > ro["peak"] and "frac_note" in ro
+            continue
         else:
             assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
         assert 0 < ro["frac"] <= 1.0, (k, ro["frac"])          # a fraction above 1 is not a roofline fraction

@@ -690,6 +690,7 @@ def test_run_rows_writes_exactly_the_range_for_every_row_class(device, oracle, N
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=2500)
     op.set_option("long_row_threshold", 256)
+    op.set_option("medium_row_threshold", 32)      # (the row classes are the subject here, not the auto rule: 2 500 columns all count as "local", auto = 256)
     op.set_option("split_long_rows", split)
     op.set_option("hub_overlap", 2)
     full = torch.empty(M, N, dtype=torch.float32, device=device)
@@ -1330,7 +1331,7 @@ def test_special_values_all_paths(device, oracle):
     B.reshape(-1)[g.integers(0, B.size, 4000)] = special[g.integers(0, special.size, 4000)]
     for opts in ({}, {"block_path": 0}, {"rows_per_block": 1000}, {"split_long_rows": 1}, {"hub_slice": 16}, {"hub_slice": 64}):
         ref = expected(oracle, ptr, idx, vals, B, opts.get("split_long_rows", 0), 256, 64)
-        o = {"long_row_threshold": 256, "long_row_chunk": 64}
+        o = {"long_row_threshold": 256, "long_row_chunk": 64, "medium_row_threshold": 32}
         o.update(opts)
         C, op = run_spmm(device, ptr, idx, vals, B, options=o)
         both_nan = np.isnan(C) & np.isnan(ref)
@@ -1449,6 +1450,7 @@ def test_wide_addressing_variants(device, oracle):
     d_C = torch.full((M, N), float("nan"), device=device)
     op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
     op.set_option("long_row_threshold", 256)
+    op.set_option("medium_row_threshold", 64)
     op.preprocess(d_B, d_C)
     assert op.get_option("n_block_groups") > 0 and op.get_option("n_long_rows") == 1 and op.get_option("n_medium_rows") >= 1
     op.run_ld(d_B, ldb, d_C, N)
@@ -1661,7 +1663,7 @@ def test_column_strips_inside_a_captured_graph(device, oracle, overlap):
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((M, N), float("nan"), device=device)
     op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
-    for k, v in {"col_strips": 4, "long_row_threshold": 1024, "hub_overlap": overlap, "segment_overlap": 1 if overlap == 2 else 0, "use_graph": 1}.items():
+    for k, v in {"col_strips": 4, "long_row_threshold": 1024, "medium_row_threshold": 32, "hub_overlap": overlap, "segment_overlap": 1 if overlap == 2 else 0, "use_graph": 1}.items():
         op.set_option(k, v)
     op.preprocess(d_B, d_C)
     assert op.get_option("n_col_strips") == 4 and op.get_option("graph_ready") == 1 and op.get_option("n_hub_rows") == 2

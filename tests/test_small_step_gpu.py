@@ -74,7 +74,7 @@ def test_small_step_roles_may_be_absent_and_ineligible_steps_keep_their_kernels(
     B = synth.normal_f32(K * N, 8).reshape(K, N)
     (d_B,) = to_dev(device, B)
     cases = {
-        "no hubs": (_graph(M, K, 1, hubs=()), {}, 1),
+        "no hubs": (_graph(M, K, 1, hubs=()), {"medium_row_threshold": 24}, 1),
         "no short rows": (synth.csr_uniform(M, 300, 600, K=K, seed=2), {"medium_row_threshold": 24, "long_row_threshold": 512}, 1),
         "only short rows": (synth.csr_uniform(M, 0, 20, K=K, seed=3), {}, 0),                # one launch anyway: nothing to fuse
         "column strips in force": (synth.csr_uniform(M, 300, 600, K=K, seed=2), {"col_strips": 3, "long_row_threshold": 1 << 30}, 0),
