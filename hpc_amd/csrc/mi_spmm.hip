@@ -63,6 +63,7 @@ struct mi_spmm_handle {
     int32_t seg_unsorted;    // segments whose columns do not ascend (-1: not looked at)
     int64_t seg_nnz;         // nonzeros in the whole segments (either plan builder): the strip rule's input, known before any column is read
     int64_t strips_builder;  // 0 (default): strip_segments, one pass; 1: the round-4 pair survey_segments + build_col_strips (cross-check)
+    int64_t seg_order;       // "segment_order": 0 = auto, 1 = segments longest first, 2 = in row order
     int64_t fused_step;      // "fused_step": 2 (default) = auto, 0 = never, 1 = whenever the step is eligible: hub rows, segments and short rows as the three
                              // roles of ONE launch (spmm_kernels.hpp spmm_small_step) instead of 2-3 launches and a side-stream fork / join
     int32_t last_fused;      // 1: the last run call went through the small-step kernel
@@ -418,7 +419,10 @@ static int ensure_side_streams(mi_spmm_handle *h)
     // profiles/r04_side_streams.txt): narrow B (N <= 64: both the rows kernel, 8 lanes per row, and the segment chains are latency-bound and fill
     // each other's gaps -- citation- and wikikg2-shaped N = 32: -8 %) and no hub stream beside it.  Everywhere else a second stream is neutral to
     // harmful (+0 .. +16 %: protein-shaped N = 32, with 1 696 hubs on their stream): the segment kernel then stays on the caller's stream.
-    const bool seg_side = h->segment_overlap == 1 || (h->segment_overlap == 2 && !h->overlap_on[0] && h->feat <= 64);
+    // Round 5 (structured graphs, profiles/r05_regret.md): where the columns are local the rows kernel is fast (its neighbours share B rows in L2) and the
+    // segment chains in front of it are what the step waits for -- beside it they cost nothing: segment_overlap = 1 is 0.78 - 0.94 of the time on
+    // yelp- / products- / ppa- / youtube- / citation-community at every width; the round-4 A/B (uniformly random columns) found it neutral to harmful there.
+    const bool seg_side = h->segment_overlap == 1 || (h->segment_overlap == 2 && ((!h->overlap_on[0] && h->feat <= 64) || h->local_pct >= 50));
     h->overlap_on[1] = seg_side && h->n_chunks > 0 && (h->hub_overlap == 2 || (h->hub_overlap == 1 && long_step));
     if (!(h->overlap_on[0] || h->overlap_on[1])) return MI_SPMM_OK;
     int lo = 0, hi = 0;
@@ -471,10 +475,10 @@ static int plan_col_strips(mi_spmm_handle *h)
     if (V == 4 && lpr > cap) lpr = cap;
     int tile = lpr * V;
     if (tile > h->feat) tile = h->feat;
-    // Columns (almost) all near the row's own position -- banded / mesh matrices: a row sits inside one or two strips, and neighbouring rows share their B rows
-    // through L2 already.  (Round 4 stopped at 50 %: a community order with 58 - 60 % of its nonzeros near the diagonal -- protein- / reddit-community -- still
-    // gathers 40 % from all over a B the caches do not hold, and strips took 33 - 43 % off its steps: profiles/r05_regret.md.)
-    if (h->col_strips == 0 && h->local_pct >= 90) return MI_SPMM_OK;
+    // (Round 4 left graphs with >= 50 % of their nonzeros near the diagonal alone: "neighbouring rows share their B rows through L2 already".  They do not
+    //  once the rows are long: protein- / reddit-community (58 - 60 % local) 0.57 - 0.67 of the time with strips, and a BANDED matrix of 300-700-nonzero rows
+    //  (100 % local: a row sits inside one or two strips) 0.54 - 0.69 -- the segment table is sorted by length, so a launch's rows come from all over the band.
+    //  The gate is gone: profiles/r05_regret.md.)
     if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz, h->front_pct) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
     if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
     void *d_sv = (char *)h->d_col_bad + 64;            // (the first bytes hold the column-range flag a second plan reads again)
@@ -560,7 +564,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         PlanOut po;
         const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
         const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
-                                      (int32_t)h->long_chunk, (int32_t)h->split_long, &h->scratch_a, &h->scratch_b, &po);
+                                      (int32_t)h->long_chunk, (int32_t)h->split_long, h->seg_order == 2 ? 2 : 1, &h->scratch_a, &h->scratch_b, &po);
         h->d_chunks = po.d_chunks;
         h->d_long = po.d_long;
         h->d_blk_groups = po.d_blk_groups;
@@ -777,6 +781,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
     else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; }
+    else if (k == "segment_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->seg_order = v; free_plan(h); }
     else if (k == "col_strips_builder") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->strips_builder = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -826,6 +831,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "segments_unsorted") *value = h->seg_unsorted;
     else if (k == "col_strips_builder") *value = h->strips_builder;
     else if (k == "fused_step") *value = h->fused_step;
+    else if (k == "segment_order") *value = h->seg_order;
     else if (k == "fused_step_in_force") *value = h->last_fused;
     else if (k == "segment_nnz") *value = h->seg_nnz;
     else if (k == "col_strips_table_hash") {           // FNV-1a over the strip tables (copied back: a test's question, not a step's)
@@ -927,7 +933,7 @@ static int preprocess_plan(mi_spmm_handle *h)
             const int32_t len = ptr[r + 1] - ptr[r];
             for (int i = 0; i < kHistN && len > hist_threshold(i); ++i) { ++hist.cnt[i]; hist.nnz[i] += (unsigned long long)len; }
         }
-        h->long_thr = resolve_hub_threshold(h->nnz, M, h->num_cols, h->feat, hist.nnz);
+        h->long_thr = resolve_hub_threshold(h->nnz, M, h->num_cols, h->feat, hist.nnz, max_len);
     }
     auto lap = [&](int i, std::chrono::steady_clock::time_point &from) {
         const auto now = std::chrono::steady_clock::now();
@@ -1002,7 +1008,7 @@ static int preprocess_plan(mi_spmm_handle *h)
     const int32_t thr = (int32_t)h->long_thr, clen = (int32_t)h->long_chunk;
     // the same auto rule as the device builder (plan.hpp resolve_medium_threshold)
     const int32_t mthr = resolve_medium_threshold((int32_t)h->medium_thr, (int32_t)(M > 0 ? h->nnz / M : 0), max_len,
-                                                  (int32_t)(h->long_thr > INT32_MAX ? INT32_MAX : h->long_thr), h->local_pct);
+                                                  (int32_t)(h->long_thr > INT32_MAX ? INT32_MAX : h->long_thr), h->local_pct, h->feat);
     h->medium_res = mthr;
     int32_t n_slots = 0, n_medium = 0;
     if (max_len > mthr) {
@@ -1045,7 +1051,8 @@ static int preprocess_plan(mi_spmm_handle *h)
         }
         // hub rows longest first, ties in row order (as the device builder's stable radix sort leaves them)
         std::stable_sort(longs.begin(), longs.end(), [](const LongRow &x, const LongRow &y) { return x.len > y.len; });
-        // longest first, stable: counting sort on the length (<= max(long_thr, long_chunk) by construction)
+        // longest first, stable: counting sort on the length (<= max(long_thr, long_chunk) by construction) -- unless the row order was asked for
+        if (h->seg_order != 2) {
         int32_t lmax = 0;
         for (const Chunk &c : chunks) lmax = std::max(lmax, c.end - c.beg);
         std::vector<int32_t> start((size_t)lmax + 2, 0);
@@ -1054,6 +1061,7 @@ static int preprocess_plan(mi_spmm_handle *h)
         std::vector<Chunk> sorted(chunks.size());
         for (const Chunk &c : chunks) sorted[(size_t)start[(size_t)(lmax - (c.end - c.beg))]++] = c;
         chunks.swap(sorted);
+        }
     }
     h->n_chunks = (int32_t)chunks.size();
     h->n_long = (int32_t)longs.size();
@@ -1216,7 +1224,7 @@ void launch_hub(int sw, bool excl, const HubArgs &a, dim3 grid, hipStream_t s)
 //   community orders (50 - 94 %: most of a row near the diagonal, the rest all over B): N >= 256 -> 128-column tiles, two rows per wavefront (round 5: six
 //     community-ordered dataset shapes and the plain block model at N = 256: 0.82 - 0.95 of the time with 256; the others neutral); narrower N: the whole row;
 //   otherwise (columns anywhere):
-//     few nonzeros per row (mean < 12: youtube-, am-, arxiv-shaped): the whole row / whole-wave tiles -- a narrower tile multiplies what a ROW costs
+//     few nonzeros per row (mean < 8: youtube-, am-, arxiv-shaped; collab-shaped, 9.7, keeps 64: 0.87): the whole row / whole-wave tiles -- a narrower tile multiplies what a ROW costs
 //       (row pointers, its lane group's start, its C store) and such a row has little else (round 5: youtube-shuffled N = 128 / 256 0.83 / 0.79,
 //       arxiv-degree N = 256 0.74, am-degree N = 256 0.82 of the time with 64);
 //     N >= 256: 64-column tiles -- the tiles are swept one after the other, so a sweep's B working set is K x 64 x 4 bytes (256 MiB at K = 2^20: the
@@ -1230,9 +1238,12 @@ int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
     if (h->local_pct < 0 || h->local_pct >= 95) return 256;
     if (h->local_pct >= 50) return N >= 256 ? 128 : 256;
     const int64_t mean = h->num_v > 0 ? h->nnz / h->num_v : 0;
-    if (mean < 12) return 256;
+    const bool hubs = (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1);
+    // (... except two tiles of 64 at N = 128 when the hubs come first in the vertex order: their B rows are the hot set, and half-width rows of it fit L2 --
+    //  am-degree N = 128: 0.88 of the time with 64; the same graph at N = 256 prefers the whole wave by 0.82)
+    if (mean < 8) return (N <= 128 && N > 64 && hubs && h->front_pct >= 50) ? 64 : 256;
     if (N >= 256) return 64;
-    if (N >= 128 && (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1)) return 64;
+    if (N >= 128 && hubs) return 64;
     return 256;
 }
 
@@ -1308,7 +1319,10 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         const bool eligible = vec4 && !wide && col_tiles == 1 && launch_blocks_here && N == full.N && h->n_strips <= 1 && !h->split_long && h->n_blk_groups == 0 &&
                               bt == kBlockThreads && pol == kPolNtStore && (h->n_long > 0 || h->n_chunks > 0) &&
                               (int64_t)((full.N + 15) / 16) * h->n_long + (int64_t)h->n_chunks + nblk64 < (int64_t)INT32_MAX;
-        const bool want = h->fused_step == 1 || (h->fused_step == 2 && step_bytes / 6e12 < 200e-6);
+        // auto: the step's bytes take under 0.1 ms, or its longest row's chain (3.2 ns per nonzero) outlasts them anyway (am-shaped): then the rows role's
+        // occupancy cannot matter.  (First rule, 0.2 ms: youtube-shaped kLen 32 -- 0.155 ms of bytes, a 75 us chain, 35 K rows workgroups -- lost 6 - 14 %.)
+        const double t_bytes = step_bytes / 6e12;
+        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < 100e-6 || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
         h->last_fused = 0;
         if (eligible && want) {
             SmallStepArgs fa{};

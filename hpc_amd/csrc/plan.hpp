@@ -30,7 +30,7 @@ struct LenHist {
     uint32_t cnt[kHistN];             // rows longer than hist_threshold(i)
     unsigned long long nnz[kHistN];   // ... and the nonzeros they hold
 };
-__host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M, int32_t K, int32_t N, const unsigned long long *nnz_above)
+__host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M, int32_t K, int32_t N, const unsigned long long *nnz_above, int32_t max_len)
 {
     const double bytes = (double)nnz * (4.0 * N + 8.0) + 4.0 * (double)M * N;
     const bool resident = 4.0 * (double)K * (double)N <= 6.0 * 1048576.0;
@@ -40,6 +40,9 @@ __host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M,
     const double seg_ns = resident ? 30.0 : 100.0 + 1.3 * (double)(N < 256 ? N : 256);
     const double idle_ns = resident ? 16.0 : 47.0;
     const double t = 0.5 * step / (seg_ns * 1e-9);
+    // the longest row itself hides behind the step as a segment: nothing needs the hub kernel (the candidates are powers of two, and the largest one
+    // below t used to send rows between it and t to the hub kernel all the same -- ddi-community kLen 256: 264 rows, 33 % regret)
+    if ((double)max_len <= t) return hist_threshold(kHistN - 1);
     int i = 0;
     while (i + 1 < kHistN && (double)hist_threshold(i + 1) <= t) ++i;
     const int i_lat = i;
@@ -56,12 +59,14 @@ __host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M,
 // where neighbours in a wave differ widely (profiles/r01_medium_threshold.txt).  Round 5: that was measured on uniformly random columns only.  Where the
 // columns are LOCAL (community / mesh order: >= 50 % of the sampled nonzeros near their row's own position) neighbouring rows gather the same B rows and
 // meet in one L2 -- in the rows kernel, which walks the rows in order; the segment table is sorted by LENGTH, which scatters exactly those neighbours over
-// the chip.  There the rows kernel keeps rows up to 256 nonzeros (profiles/r05_regret.md: ppa- / products- / yelp- / citation-community 64 -> 0.85,
-// 128 -> 0.72 - 0.77 of the time at 32; non-local orders of the same graphs: 64 and 128 LOSE 16 - 38 %).
-__host__ __device__ inline int32_t resolve_medium_threshold(int32_t mthr_user, int32_t mean_len, int32_t max_len, int32_t thr, int32_t local_pct)
+// the chip.  There, at N >= 128 (at most two rows per wavefront: a long row next to a short one idles little), the rows kernel keeps rows up to 512 nonzeros
+// (profiles/r05_regret.md: ppa- / products- / yelp- / citation-community 64 -> 0.85, 128 -> 0.72 - 0.77, 512 -> a further 0.91 - 0.95 of the time; banded
+// long rows 512 -> 0.65; non-local orders of the same graphs: 64 and 128 LOSE 16 - 38 %).  At N < 128 (eight or four rows per wavefront) a long row idles its
+// neighbours' lanes and the old rule stays (collab- / youtube- / yelp-community kLen 32: 256 loses 22 - 34 %).
+__host__ __device__ inline int32_t resolve_medium_threshold(int32_t mthr_user, int32_t mean_len, int32_t max_len, int32_t thr, int32_t local_pct, int32_t N)
 {
     int32_t m = mthr_user > 0 ? mthr_user
-              : local_pct >= 50 ? 256
+              : (local_pct >= 50 && N >= 128) ? 512
               : ((int64_t)max_len > 8 * (int64_t)(mean_len > 1 ? mean_len : 1) ? 32 : 64);
     return m < thr ? m : thr;
 }
@@ -96,8 +101,9 @@ void scratch_release(Scratch *s);
 // N: dense width (the auto rule's byte estimate).
 // the column sample on its own (the host plan builder has no device pass of its own over the rows): synchronises
 int sample_columns_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int64_t nnz, void *d_scratch256, int32_t *local_pct, int32_t *front_pct);
+// seg_order: 1 = segments longest first (stable), 2 = in row order (no sort)
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int32_t N, int64_t nnz,
-                   const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, int32_t split,
+                   const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr, int32_t clen, int32_t split, int32_t seg_order,
                    Scratch *sa, Scratch *sb, PlanOut *out);
 
 // ---- column strips of the exact segments --------------------------------------------------------------------------

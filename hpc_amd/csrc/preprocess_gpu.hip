@@ -107,9 +107,9 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
     int len = 0;
     unsigned bad = 0;
     // max_len and the histogram are complete (previous kernel); every thread resolves the same two thresholds
-    const int thr = thr_user > 0 ? thr_user : resolve_hub_threshold(nnz, M, K, N, stats->hist.nnz);
+    const int thr = thr_user > 0 ? thr_user : resolve_hub_threshold(nnz, M, K, N, stats->hist.nnz, stats->max_len);
     const int local_pct = stats->sampled > 0 ? (int)(100.0 * stats->near / stats->sampled) : 0;      // (sample_locality ran before this kernel, same stream)
-    const int mthr = resolve_medium_threshold(mthr_user, mean_len, stats->max_len, thr, local_pct);
+    const int mthr = resolve_medium_threshold(mthr_user, mean_len, stats->max_len, thr, local_pct, N);
     if (r < M) {
         const int beg = row_ptr[r], end = row_ptr[r + 1];
         len = end - beg;
@@ -257,7 +257,7 @@ int sample_columns_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32
 }
 
 int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M, int32_t K, int32_t N, int64_t nnz,
-                   const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr_user, int32_t clen, int32_t split,
+                   const uint8_t *d_blk_flag, const unsigned int *d_col_bad, int32_t mthr, int32_t thr_user, int32_t clen, int32_t split, int32_t seg_order,
                    Scratch *sa, Scratch *sb, PlanOut *out)
 {
     *out = PlanOut();
@@ -390,7 +390,8 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                            dim3(kBlockThreads), 0, 0, d_row_ptr, M, thr, clen, seg_cnt, seg_off, slot_off, long_off,
                            unsorted, keys_in, longs_unsorted, lkeys_in);
         PLAN_TRY(hipGetLastError());
-        if (n > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
+        if (n > 0 && seg_order == 2) PLAN_TRY(hipMemcpyAsync(out->d_chunks, unsorted, n * sizeof(Chunk), hipMemcpyDeviceToDevice, 0));      // row order: as emitted
+        else if (n > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
         if (nl > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, lbytes, lkeys_in, lkeys_out, longs_unsorted, out->d_long, (int)nl, 0, end_bit));
     }
     PLAN_TRY(hipStreamSynchronize(0));

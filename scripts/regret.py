@@ -109,12 +109,26 @@ def summarize(path):
     print("Graphs: `hpc_amd/synth.py` `csr_dcsbm_device` (degree-corrected block model with the rows / nonzeros / longest row of the reference's datasets, symmetric: hub rows are hub columns), "
           "order = community (a BFS / RCM / partitioner order), shuffled, degree (hubs first); `-rcm`: a true reverse Cuthill-McKee order (scipy); `-unsorted`: columns in random order inside a row; "
           "`rmat20-unpermuted`; `sbm`: equal degrees, dense diagonal blocks.  `auto` and `best forced` re-timed interleaved; regret = auto / best - 1.\n")
-    print("| graph | rows | nnz | longest row | locality % | kLen | auto ms | best forced ms | regret % | best forced setting | auto's resolved setting | settings tried | bit-different settings |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| graph | rows | nnz | longest row | locality % | kLen | auto ms | best forced ms | regret % | best forced setting | single options that beat auto by > 4 % (time ratio) | auto's resolved setting | settings tried | bit-different settings | auto vs spmm_kernel_ref (differing elements) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     worst = []
+    short = {"long_row_threshold": "thr", "col_strips": "strips", "tile_cols": "tile", "medium_row_threshold": "mthr", "segment_overlap": "seg_ov", "hub_overlap": "hub_ov",
+             "hub_slice": "slice", "fused_step": "fused", "segment_order": "seg_order"}
+
+    def fmt(cfg):
+        return ", ".join(f"{short.get(k, k)}={'none' if v == NONE_THR else v}" for k, v in cfg.items()) or "(auto)"
+
     for r in rows:
-        print(f"| {r['graph']} | {r['M']} | {r['nnz']} | {r['max_row']} | {r['auto_cfg'].get('locality_pct', '')} | {r['N']} | {r['auto_ms']:.4f} | {r['best_ms']:.4f} | {r['regret_pct']:.1f} | "
-              f"{r['best_cfg']} | {r['auto_cfg']} | {r['n_tried']} | {r['n_bitdiff']} |")
+        a = r["auto_cfg"]
+        singles = []
+        for k, d in (r.get("one_at_a_time_vs_auto") or {}).items():
+            best_v = min(((v, kk) for kk, v in d.items() if v), default=None)
+            if best_v and best_v[0] < 0.96:
+                singles.append(f"{short.get(k, k)}={best_v[1]}: {best_v[0]:.2f}")
+        auto_s = (f"thr {a['thr'] if a['thr'] != NONE_THR else 'none'}, strips {a['S']}, tile {a['tile']}, mthr {a['mthr']}, {a['hubs']} hubs, {a['segments']} segments ({a['seg_nnz_pct']} % of nnz), "
+                  f"{a['launches']} launch{'es' if a['launches'] != 1 else ''}{', small-step kernel' if a.get('fused') else ''}, front {a.get('front_pct')} %, preprocess {a['preprocess_us']} us")
+        print(f"| {r['graph']} | {r['M']} | {r['nnz']} | {r['max_row']} | {a.get('locality_pct', '')} | {r['N']} | {r['auto_ms']:.4f} | {r['best_ms']:.4f} | {r['regret_pct']:.1f} | "
+              f"{fmt(r['best_cfg'])} | {'; '.join(singles) or '-'} | {auto_s} | {r['n_tried']} | {r['n_bitdiff']} | {r.get('auto_bitdiff_vs_spmm_kernel_ref')} |")
         worst.append((r["regret_pct"], r["graph"], r["N"]))
     worst.sort(reverse=True)
     print(f"\nmax regret {worst[0][0]:.1f} % ({worst[0][1]}, kLen {worst[0][2]}); entries above 10 %: {sum(1 for w in worst if w[0] > 10)} of {len(worst)}; "
@@ -237,7 +251,7 @@ def main():
 
             # one option at a time from auto: which RULE is at fault when the best forced setting changes several at once
             marg = {}
-            for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128, 256, 512]),
+            for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128, 256, 512, 1024]), ("segment_order", [1, 2]),
                                 ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else []), ("fused_step", [0, 1])):
                 for v_ in vals_:
                     consider({key_: v_})
@@ -269,8 +283,11 @@ def main():
                     for extra in hub_dims(cur):
                         consider(dict(cur, **extra))
                     cur = dict(best[0])
-                    for m in (32, 64, 128, 256, 512):
+                    for m in (32, 64, 128, 256, 512, 1024):
                         consider(dict(cur, medium_row_threshold=m))
+                    cur = dict(best[0])
+                    for so in (1, 2):
+                        consider(dict(cur, segment_order=so))
                     cur = dict(best[0])
                     for ho in (0, 2):
                         consider(dict(cur, hub_overlap=ho))
@@ -286,8 +303,11 @@ def main():
             # the medium threshold and hub_overlap for the small graphs too (coordinate sweeps at the best point)
             if nnz < args.full_grid_below:
                 cur = dict(best[0])
-                for m in (32, 64, 128, 256, 512):
+                for m in (32, 64, 128, 256, 512, 1024):
                     consider(dict(cur, medium_row_threshold=m))
+                cur = dict(best[0])
+                for so in (1, 2):
+                    consider(dict(cur, segment_order=so))
                 cur = dict(best[0])
                 for ho in (0, 2):
                     consider(dict(cur, hub_overlap=ho))

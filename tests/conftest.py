@@ -127,6 +127,10 @@ def auto_hub_threshold(M, N, ptr, K=None):
     idle_ns = 16.0 if resident else 47.0
     t = 0.5 * step / (seg_ns * 1e-9)
     cand = [256 << i for i in range(6)]
+    if deg.size and float(deg.max()) <= t:        # the longest row itself hides as a segment: no hubs at all
+        return cand[-1]
+    if deg.size and float(deg.max()) <= t:        # the longest row itself hides as a segment: no hubs at all
+        return cand[-1]
     i = 0
     while i + 1 < 6 and cand[i + 1] <= t:
         i += 1
