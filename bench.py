@@ -471,6 +471,8 @@ def main():
                     "GBs_on_bytes_min": round(model["bytes_min"] / (dev_ms_mean * 1e-3) / 1e9, 1),
                     "block_items": {k: op.get_option(k) for k in ("n_block_groups", "n_block_pieces", "n_block_items", "n_block_shared_items",
                                                                   "n_block_passes")}}
+        elif achieved is not None and not multi and name != "C1" and 4.0 * M * n_loc <= 256 * 1048576:      # (C1 is the contract line: "hbm"; its B is 512 MiB at the contract's size)
+            roof = cache_resident_roofline(model, dev_ms_mean, traffic, traffic_source, M, n_loc, op.get_option("n_launches"))
         elif achieved is not None:
             roof = {"bound": "hbm", "bound_detail": "l2_fabric (gather model): algorithmic bytes over the L2<->fabric path, Infinity-Cache hits "
                     "included; the contract's token stays \"hbm\", the HBM copy ceiling is frac_of_measured_copy_6290's denominator",
@@ -779,6 +781,30 @@ def main():
         wd.disarm()
 
 
+def cache_resident_roofline(model, ms, traffic, src, M, n, launches):
+    """B fits the Infinity Cache (4 K N <= 256 MiB) -- and, strip by strip, an XCD's L2: the gather model's bytes are NOT what the memory system moves, so a
+    fraction of the HBM peak on them can exceed 1 (round 4 printed 2.25 under "hbm").  The honest bound: what crossed the L2 <-> fabric side (PMC) over the
+    step, against the fabric's 8 TB/s; without counters, the gather model against the L2-resident gather rate of the guide (18.8 TB/s) -- and no fraction at
+    all when even that is exceeded (a B of a few MiB with ascending columns is served in front of the L2)."""
+    gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
+    if traffic is not None:
+        ach = traffic / (ms * 1e-3) / 1e9
+        roof = {"bound": "fabric", "bound_detail": "B is cache-resident (4 K N <= 256 MiB): measured L2<->fabric bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) "
+                "per step over this run's step time, against the fabric's 8 TB/s", "peak": HBM_PEAK_GBS, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+    else:
+        roof = {"bound": "l2_gather", "bound_detail": "B is cache-resident (4 K N <= 256 MiB) and no counters are at hand: gather-model bytes against the "
+                "L2-resident gather rate (MI355X_MICROARCH.md \"Indexed rows\": 16.8-18.8 TB/s chip-wide)", "peak": 18800.0, "achieved": round(gbs, 1),
+                "frac": round(gbs / 18800.0, 4)}
+        if gbs > 18800.0:
+            roof["frac"] = None
+            roof["frac_note"] = "achieved exceeds the cited L2 gather rate: the gathers are served in front of the L2 (vector L1); no fraction is claimed"
+    roof.update({"kernel": "mi::spmm_chunks (column strips) + mi::spmm_rows_v2", "unit": "GB/s", "achieved_alg": round(gbs, 1),
+                 "achieved_alg_note": "gather-model bytes / step time: served mostly by L2 and the Infinity Cache, not a fraction of any memory peak",
+                 "b_bytes": int(4 * M * n), "bytes_alg": model["bytes_alg"], "bytes_min": model["bytes_min"], "traffic": traffic, "traffic_source": src,
+                 "launches_per_step": launches})
+    return roof
+
+
 def traffic_staleness(entry):
     """Is a profiles/traffic_latest.json entry about the kernels this run executes?  The entry carries the sha256 of the
     kernel sources it was measured on (hpc_amd/_lib.py KERNEL_SOURCES); `traffic_stale` = that hash is absent or differs
@@ -866,25 +892,7 @@ def also_configs(args, dev, c1_tensors, M):
                     "GBs_on_bytes_alg": round(gbs, 1), "bytes_floor_ms": round(model["bytes_alg"] / 8e12 * 1e3, 4),
                     "traffic": traffic, "traffic_source": src, "launches_per_step": op.get_option("n_launches"), "n_hub_rows": op.get_option("n_hub_rows")}
         elif 4.0 * M * n <= 256 * 1048576:
-            # B fits the Infinity Cache (and, strip by strip, an XCD's L2): the gather model's bytes are NOT what the memory system moves, so a fraction of the
-            # HBM peak on them can exceed 1 (round 4 printed 2.25 under "hbm").  The honest bound: what crossed the L2 <-> fabric side (PMC) over the step,
-            # against the fabric's 8 TB/s; without counters, the gather model against the L2-resident gather rate of the guide (18 TB/s).
-            gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
-            if traffic is not None:
-                ach = traffic / (ms * 1e-3) / 1e9
-                roof = {"bound": "fabric", "bound_detail": "B is cache-resident (4 K N <= 256 MiB): measured L2<->fabric bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) "
-                        "per step over this run's step time, against the fabric's 8 TB/s", "peak": HBM_PEAK_GBS, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
-            else:
-                roof = {"bound": "l2_gather", "bound_detail": "B is cache-resident (4 K N <= 256 MiB) and no counters are at hand: gather-model bytes against the "
-                        "L2-resident gather rate (MI355X_MICROARCH.md \"Indexed rows\": 16.8-18.8 TB/s chip-wide)", "peak": 18800.0, "achieved": round(gbs, 1),
-                        "frac": round(gbs / 18800.0, 4)}
-                if gbs > 18800.0:       # a B of a few MiB with ascending columns: consecutive nonzeros of a row hit the same lines in the vector L1, in front of
-                    roof["frac"] = None  # the L2 -- no cited peak applies to that, and a fraction above 1 is not a roofline fraction (down-sized runs only)
-                    roof["frac_note"] = "achieved exceeds the cited L2 gather rate: the gathers are served in front of the L2 (vector L1); no fraction is claimed"
-            roof.update({"kernel": "mi::spmm_chunks (column strips) + mi::spmm_rows_v2", "unit": "GB/s", "achieved_alg": round(gbs, 1),
-                         "achieved_alg_note": "gather-model bytes / step time: served mostly by L2 and the Infinity Cache, not a fraction of any memory peak",
-                         "b_bytes": int(4 * M * n), "bytes_alg": model["bytes_alg"], "bytes_min": model["bytes_min"], "traffic": traffic, "traffic_source": src,
-                         "launches_per_step": op.get_option("n_launches")})
+            roof = cache_resident_roofline(model, ms, traffic, src, M, n, op.get_option("n_launches"))
         else:
             gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "bound_detail": "l2_fabric (gather model): algorithmic bytes over the L2<->fabric path, Infinity-Cache hits included",

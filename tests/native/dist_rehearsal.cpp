@@ -62,6 +62,11 @@ int main()
             int64_t off = 0;
             CK(mi_spmm_dist_export_c(d, d_C, handle, &off));     // a multi-rank host all-gathers handles and offsets
             CK(mi_spmm_dist_set_peers(d, d_C, handle, &off));
+            // the link probe a multi-rank host runs once after set_peers; a world of one has no peer: every rate 0, nothing copied
+            double per_peer[1] = {-1.0}, all_peers = -1.0;
+            int32_t link_type[1] = {0}, hops[1] = {0};
+            CK(mi_spmm_dist_link_probe(d, d_C, 0, nullptr, per_peer, &all_peers, link_type, hops));
+            if (per_peer[0] != 0.0 || all_peers != 0.0 || link_type[0] != -1 || hops[0] != -1) { std::fprintf(stderr, "link probe at world 1: unexpected result\n"); return 3; }
         }
         CK(hipMemsetAsync(d_C, 0xff, sizeof(float) * (size_t)M * N, stream));   // NaN pattern
         for (int it = 0; it < 3; ++it) CK(mi_spmm_dist_run(d, d_B, d_C, (void *)stream));
