@@ -564,7 +564,7 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         PlanOut po;
         const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
         const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
-                                      (int32_t)h->long_chunk, (int32_t)h->split_long, h->seg_order == 2 ? 2 : 1, &h->scratch_a, &h->scratch_b, &po);
+                                      (int32_t)h->long_chunk, (int32_t)h->split_long, (int32_t)h->seg_order, &h->scratch_a, &h->scratch_b, &po);
         h->d_chunks = po.d_chunks;
         h->d_long = po.d_long;
         h->d_blk_groups = po.d_blk_groups;
@@ -1007,7 +1007,7 @@ static int preprocess_plan(mi_spmm_handle *h)
     std::vector<LongRow> longs;
     const int32_t thr = (int32_t)h->long_thr, clen = (int32_t)h->long_chunk;
     // the same auto rule as the device builder (plan.hpp resolve_medium_threshold)
-    const int32_t mthr = resolve_medium_threshold((int32_t)h->medium_thr, (int32_t)(M > 0 ? h->nnz / M : 0), max_len,
+    const int32_t mthr = resolve_medium_threshold((int32_t)h->medium_thr, h->nnz, M, max_len,
                                                   (int32_t)(h->long_thr > INT32_MAX ? INT32_MAX : h->long_thr), h->local_pct, h->feat);
     h->medium_res = mthr;
     int32_t n_slots = 0, n_medium = 0;
@@ -1052,7 +1052,7 @@ static int preprocess_plan(mi_spmm_handle *h)
         // hub rows longest first, ties in row order (as the device builder's stable radix sort leaves them)
         std::stable_sort(longs.begin(), longs.end(), [](const LongRow &x, const LongRow &y) { return x.len > y.len; });
         // longest first, stable: counting sort on the length (<= max(long_thr, long_chunk) by construction) -- unless the row order was asked for
-        if (h->seg_order != 2) {
+        if (!(h->seg_order == 2 || (h->seg_order == 0 && h->local_pct >= 50 && !h->split_long))) {       // (auto: plan.hpp segment_order_is_rows)
         int32_t lmax = 0;
         for (const Chunk &c : chunks) lmax = std::max(lmax, c.end - c.beg);
         std::vector<int32_t> start((size_t)lmax + 2, 0);
@@ -1319,10 +1319,11 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         const bool eligible = vec4 && !wide && col_tiles == 1 && launch_blocks_here && N == full.N && h->n_strips <= 1 && !h->split_long && h->n_blk_groups == 0 &&
                               bt == kBlockThreads && pol == kPolNtStore && (h->n_long > 0 || h->n_chunks > 0) &&
                               (int64_t)((full.N + 15) / 16) * h->n_long + (int64_t)h->n_chunks + nblk64 < (int64_t)INT32_MAX;
-        // auto: the step's bytes take under 0.1 ms, or its longest row's chain (3.2 ns per nonzero) outlasts them anyway (am-shaped): then the rows role's
+        // auto: the step's bytes take under 0.12 ms, or its longest row's chain (3.2 ns per nonzero) outlasts them anyway (am-shaped): then the rows role's
         // occupancy cannot matter.  (First rule, 0.2 ms: youtube-shaped kLen 32 -- 0.155 ms of bytes, a 75 us chain, 35 K rows workgroups -- lost 6 - 14 %.)
-        const double t_bytes = step_bytes / 6e12;
-        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < 100e-6 || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
+        // (an L2-resident B -- 4 K N <= 6 MiB, ddi-shaped -- moves its bytes three times faster: priced as in plan.hpp resolve_hub_threshold)
+        const double t_bytes = step_bytes / (4.0 * (double)h->num_cols * (double)full.N <= 6.0 * 1048576.0 ? 18e12 : 6e12);
+        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < 120e-6 || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
         h->last_fused = 0;
         if (eligible && want) {
             SmallStepArgs fa{};
@@ -1385,7 +1386,9 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
             //  of a row cost more than they save: am-shaped 1.164 -> 1.119 ms with 32; 64 loses everywhere it is the chain that counts)
             const bool chain_bound = full.N <= 128 && (double)h->max_row_nnz * 3.3e-9 > 0.5 * step_s;
             sw = (full.N <= 16 || chain_bound) ? 16 : 32;
-            excl = chain_bound;
+            // ... and only while the hub workgroups are few: each keeps a whole CU, and 184 hubs x 8 slices of them (am-community N = 128) held the chip
+            // until the last one had gone -- the rows kernel behind them started late: 0.43 -> 0.57 ms (profiles/r05_regret.md)
+            excl = chain_bound && (int64_t)((full.N + 15) / 16) * h->n_long <= 128;
         }
         const bool wide_hub = !((int64_t)h->num_cols <= (1 << 24) && ldb * 4 < (1 << 24) &&
                                 ((int64_t)(h->num_cols > 0 ? h->num_cols - 1 : 0) * ldb + full.N) * 4 <= ((int64_t)1 << 32));

@@ -54,20 +54,33 @@ __host__ __device__ inline int32_t resolve_hub_threshold(int64_t nnz, int32_t M,
     return hist_threshold(i);
 }
 
-// ---- auto medium threshold (rows above it leave the rows kernel for the length-sorted segment kernel) -------------------------------------
+// ---- auto medium threshold (rows above it leave the rows kernel for the segment kernel) -----------------------------------------------------
 // 64 when the degrees are even (the rows kernel's lane groups finish together anyway), 32 when the longest row is more than 8x the mean -- skewed graphs,
 // where neighbours in a wave differ widely (profiles/r01_medium_threshold.txt).  Round 5: that was measured on uniformly random columns only.  Where the
 // columns are LOCAL (community / mesh order: >= 50 % of the sampled nonzeros near their row's own position) neighbouring rows gather the same B rows and
-// meet in one L2 -- in the rows kernel, which walks the rows in order; the segment table is sorted by LENGTH, which scatters exactly those neighbours over
-// the chip.  There, at N >= 128 (at most two rows per wavefront: a long row next to a short one idles little), the rows kernel keeps rows up to 512 nonzeros
-// (profiles/r05_regret.md: ppa- / products- / yelp- / citation-community 64 -> 0.85, 128 -> 0.72 - 0.77, 512 -> a further 0.91 - 0.95 of the time; banded
-// long rows 512 -> 0.65; non-local orders of the same graphs: 64 and 128 LOSE 16 - 38 %).  At N < 128 (eight or four rows per wavefront) a long row idles its
-// neighbours' lanes and the old rule stays (collab- / youtube- / yelp-community kLen 32: 256 loses 22 - 34 %).
-__host__ __device__ inline int32_t resolve_medium_threshold(int32_t mthr_user, int32_t mean_len, int32_t max_len, int32_t thr, int32_t local_pct, int32_t N)
+// meet in one L2 in the rows kernel, which walks the rows in order and many at a time; a row that leaves it loses that company.  So, on local orders:
+//   N >= 128 (at most two rows per wavefront: a long row next to a short one idles little), a graph large enough to fill the chip with rows (M >= 65 536) and
+//     a step long enough not to be latency-bound (>= 0.2 ms of bytes at 6 TB/s): the rows kernel keeps rows up to 512 nonzeros (profiles/r05_regret.md:
+//     ppa- / products- / yelp- / citation-community 64 -> 0.85, 128 -> 0.72 - 0.77, 512 -> a further 0.91 - 0.95 of the time; ddi- (4 267 rows) and
+//     arxiv-community (0.1 ms steps) LOSE 20 - 45 % with it: few rows, each needing the segment kernel's 32 gathers in flight);
+//   N < 128 (eight or four rows per wavefront: a long row idles its neighbours' lanes): four times the mean degree, at most 256 -- on graphs whose ROWS ARE
+//     long (ppa-, products-, protein-shaped: mean 48 - 600) a threshold of 32 sends nearly every row away (ppa-community kLen 32: 256 -> 0.79), on graphs of
+//     short rows with a few long ones (collab-, youtube-, yelp-shaped: mean 5 - 19) the old rule stays (256 there loses 22 - 34 %).
+// Non-local orders of the same graphs: 64 and 128 LOSE 16 - 38 % against 32.
+__host__ __device__ inline int32_t resolve_medium_threshold(int32_t mthr_user, int64_t nnz, int32_t M, int32_t max_len, int32_t thr, int32_t local_pct, int32_t N)
 {
-    int32_t m = mthr_user > 0 ? mthr_user
-              : (local_pct >= 50 && N >= 128) ? 512
-              : ((int64_t)max_len > 8 * (int64_t)(mean_len > 1 ? mean_len : 1) ? 32 : 64);
+    const int64_t mean_len = M > 0 ? nnz / M : 0;
+    const int32_t old_rule = (int64_t)max_len > 8 * (mean_len > 1 ? mean_len : 1) ? 32 : 64;
+    int32_t m = old_rule;
+    if (mthr_user > 0) m = mthr_user;
+    else if (local_pct >= 50) {
+        const double step = ((double)nnz * (4.0 * N + 8.0) + 4.0 * (double)M * N) / 6e12;
+        if (N >= 128) { if (M >= 65536 && step >= 200e-6) m = 512; }
+        else {
+            const int64_t by_mean = 4 * mean_len;
+            if (by_mean > m) m = (int32_t)(by_mean < 256 ? by_mean : 256);
+        }
+    }
     return m < thr ? m : thr;
 }
 
@@ -135,7 +148,9 @@ inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz,
     // Measured on protein- and reddit-shaped graphs at N = 32 / 128 / 256, strip counts interleaved in one process (profiles/r04_col_strips.txt, sections 2
     // and 9): the best strip holds 4 - 6 MiB of B per column tile (one to one and a half XCD L2s; smaller strips pay more launches and shorter sub-segments
     // than they gain in hits), sub-segments down to ~20 nonzeros still pay with 16 gathers in flight, and a strip that cannot get below 16 MiB buys nothing.
-    if (n_segments <= 0 || seg_nnz * 2 < nnz) return 1;                 // the segments are not where the step's bytes are
+    // the segments are not where the step's bytes are.  (A quarter, round 5; it was half: reddit-community at N >= 128 keeps its rows up to 512 nonzeros
+    // in the rows kernel -- the medium rule above -- and the longer ones, 40 % of the nonzeros, still gain 0.70 - 0.79 of the step's time from strips.)
+    if (n_segments <= 0 || seg_nnz * 4 < nnz) return 1;
     const double strip_target = 5.0 * 1048576.0;
     const double b_bytes = (double)K * 4.0 * (double)tile_cols;
     int64_t s = (int64_t)(b_bytes / strip_target + 0.5);

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_rows(const int32_t *__
     // max_len and the histogram are complete (previous kernel); every thread resolves the same two thresholds
     const int thr = thr_user > 0 ? thr_user : resolve_hub_threshold(nnz, M, K, N, stats->hist.nnz, stats->max_len);
     const int local_pct = stats->sampled > 0 ? (int)(100.0 * stats->near / stats->sampled) : 0;      // (sample_locality ran before this kernel, same stream)
-    const int mthr = resolve_medium_threshold(mthr_user, mean_len, stats->max_len, thr, local_pct, N);
+    const int mthr = resolve_medium_threshold(mthr_user, nnz, M, stats->max_len, thr, local_pct, N);
     if (r < M) {
         const int beg = row_ptr[r], end = row_ptr[r + 1];
         len = end - beg;
@@ -390,7 +390,11 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                            dim3(kBlockThreads), 0, 0, d_row_ptr, M, thr, clen, seg_cnt, seg_off, slot_off, long_off,
                            unsorted, keys_in, longs_unsorted, lkeys_in);
         PLAN_TRY(hipGetLastError());
-        if (n > 0 && seg_order == 2) PLAN_TRY(hipMemcpyAsync(out->d_chunks, unsorted, n * sizeof(Chunk), hipMemcpyDeviceToDevice, 0));      // row order: as emitted
+        // segment order: by length (the lane groups of a wave carry similar lengths, the tail is short) -- or, where the columns are local, AS THE ROWS COME:
+        // the segment table sorted by length scatters neighbouring rows (which gather the same B rows) over the chip; in row order they meet in one L2 like the
+        // rows kernel's (round 5: banded long rows 0.55, protein-unsorted 0.89, reddit-community 0.92 of the time; profiles/r05_regret.md).  auto = 0.
+        const bool by_rows = seg_order == 2 || (seg_order == 0 && out->local_pct >= 50 && !split);
+        if (n > 0 && by_rows) PLAN_TRY(hipMemcpyAsync(out->d_chunks, unsorted, n * sizeof(Chunk), hipMemcpyDeviceToDevice, 0));      // row order: as emitted
         else if (n > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
         if (nl > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, lbytes, lkeys_in, lkeys_out, longs_unsorted, out->d_long, (int)nl, 0, end_bit));
     }
