@@ -413,6 +413,20 @@ def csr_rmat_device(scale, device, edge_factor=32, a=0.57, b=0.19, c=0.19, seed=
     return _csr_from_pairs_device(rows, cols, M, M, sort_cols=sort_cols, seed=seed)
 
 
+def csr_banded_long_rows_device(M, device, width=2048, lo=300, hi=700, seed=7):
+    """Every column within +-width of the row's own index (mesh / banded), lo..hi nonzeros per row: long rows whose columns sit inside one or two column
+    strips -- the structure round 4's strip rule excluded by its locality gate (scripts/regret.py: strips and row-ordered segments halve its steps)."""
+    import torch
+
+    dev = torch.device(device)
+    deg = torch.from_numpy(_rng(seed, 7).integers(lo, hi + 1, size=M)).to(dev)
+    rows = torch.repeat_interleave(torch.arange(M, device=dev), deg)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    off = torch.randint(-width, width + 1, (rows.numel(),), generator=gen, device=dev)
+    return _csr_from_pairs_device(rows, (rows + off).clamp_(0, M - 1), M, M)
+
+
 def csr_reorder_rcm(ptr, idx):
     """A true reverse Cuthill-McKee ordering (scipy, host) of a graph given as numpy CSR: rows and columns relabelled by the same permutation, columns
     re-sorted.  For the small dataset shapes (seconds up to a few million nonzeros); the larger ones use order = "community" instead."""

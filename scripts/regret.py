@@ -65,24 +65,12 @@ def graph_list(quick):
         "reddit-community": ds("reddit.dgl"), "reddit-degree": ds("reddit.dgl", order="degree"),
         "products-community": ds("products"),
         # every column within +-2048 of the row (mesh-like): 300-700 nonzeros per row -> segments whose rows sit inside one or two column strips
-        "banded-long-rows": lambda dev: _banded_long_rows(dev),
+        "banded-long-rows": lambda dev: synth.csr_banded_long_rows_device(1 << 17, dev),
         "banded-deg32": lambda dev: tuple(__import__("torch").from_numpy(a).to(dev) for a in synth.csr_banded(1 << 20)),
     }
     if quick:
         g = {k: g[k] for k in ("arxiv-community", "ddi-community", "youtube-community", "protein-community")}
     return g
-
-
-def _banded_long_rows(dev, M=1 << 17, width=2048, lo=300, hi=700):
-    import torch
-    from hpc_amd import synth
-
-    deg = torch.from_numpy(synth._rng(7, 7).integers(lo, hi + 1, size=M)).to(dev)
-    rows = torch.repeat_interleave(torch.arange(M, device=dev), deg)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(7)
-    off = torch.randint(-width, width + 1, (rows.numel(),), generator=gen, device=dev)
-    return synth._csr_from_pairs_device(rows, (rows + off).clamp_(0, M - 1), M, M)
 
 
 class Timer:

@@ -371,3 +371,49 @@ def test_long_rows_device_generator_full_size_against_the_reference_kernel(devic
         hashes.append(op.get_option("col_strips_table_hash"))
         print(f"LONG_ROWS builder {builder}: preprocess {op.get_option('preprocess_us')} us, strips {op.get_option('n_col_strips')}")
     assert hashes[0] == hashes[1] != 0
+
+
+# Round 5: the graphs the auto rules were worst on (profiles/r05_regret_before_rule_fixes.md / r05_regret.md), at the regret suite's sizes, default options,
+# whole C against spmm_kernel_ref -- with the plan the fixed rules now choose pinned beside the bits, so that a rule that drifts back shows up here.
+_STRUCTURED = {
+    # name: (builder, N, what the plan must look like)
+    "reddit-community": (lambda dev: synth.csr_dataset_structured_device("reddit.dgl", dev), 256,
+                         lambda o: o("n_col_strips") >= 8 and o("segments_unsorted") == 0 and o("column_locality_pct") >= 50),          # 60 % local: round 4's gate kept strips off (+77 %)
+    "banded-long-rows": (lambda dev: synth.csr_banded_long_rows_device(1 << 17, dev), 128,
+                         lambda o: o("column_locality_pct") >= 95 and o("medium_row_threshold") >= 512),                              # rows stay with their neighbours (+89 % before)
+    "protein-unsorted": (lambda dev: synth.csr_dataset_structured_device("protein", dev, sort_cols=False), 128,
+                         lambda o: o("n_col_strips") == 1 and (o("segments_unsorted") > 0 or o("n_chunks") == 0 or o("segments_unsorted") == -1)),   # columns in random order: no strips, still every bit
+    "rmat20-unpermuted": (lambda dev: synth.csr_rmat_device(20, dev), 256,
+                          lambda o: o("column_front_pct") >= 50 and o("n_col_strips") == 4 and o("n_hub_rows") > 0),                     # hubs-first order: four wide strips (+16 % before)
+    "ddi-community": (lambda dev: synth.csr_dataset_structured_device("ddi", dev), 256,
+                      lambda o: o("n_hub_rows") == 0),                                                                                 # L2-resident B: the longest row hides as a segment (+33 % before)
+}
+
+
+@pytest.mark.parametrize("name", list(_STRUCTURED))
+def test_structured_graphs_default_options_bit_identical_to_reference_kernel(device, oracle, name):
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd.spmm import count_bitdiff, fill_normal
+
+    build, N, plan_ok = _STRUCTURED[name]
+    d_ptr, d_idx = build(device)
+    M, nnz = d_ptr.numel() - 1, int(d_idx.numel())
+    d_val = torch.empty(nnz, dtype=torch.float32, device=device)
+    fill_normal(d_val, 124)
+    d_B = torch.empty(M * N, dtype=torch.float32, device=device)
+    fill_normal(d_B, 125)
+    d_B = d_B.view(M, N)
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), N)
+    op.set_option("fused_step", 2)              # the library's defaults throughout (conftest's session default is 0)
+    op.preprocess(d_B, d_C)
+    assert plan_ok(op.get_option), {k: op.get_option(k) for k in ("n_col_strips", "segments_unsorted", "column_locality_pct", "column_front_pct", "medium_row_threshold",
+                                                                  "long_row_threshold", "n_hub_rows", "n_chunks")}
+    op.run(d_B, d_C)
+    op.run(d_B, d_C)
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    assert count_bitdiff(d_C, d_R) == (0, 0.0), name

@@ -98,3 +98,12 @@ def test_dataset_structured_shapes():
     M, nnz, mx = synth.DATASET_SHAPES["ddi"]
     assert p.numel() == M + 1 and 0.7 * nnz < i.numel() <= nnz
     assert int(torch.diff(p).max()) > 0.5 * mx
+
+
+def test_banded_long_rows_stay_inside_their_band():
+    p, i = synth.csr_banded_long_rows_device(4096, "cpu", width=256, lo=30, hi=70)
+    ptr, idx = p.numpy(), i.numpy()
+    _check_csr(ptr, idx, 4096)
+    assert (np.abs(idx - _rows(ptr)) <= 256).all()
+    deg = np.diff(ptr)
+    assert deg.min() >= 20 and deg.max() <= 70          # (duplicates dropped: a little under the drawn 30 .. 70)
