@@ -90,15 +90,20 @@ class Timer:
         return self.a.elapsed_time(self.b) / reps
 
 
-def summarize(path):
+def summarize(path, before=None):
     rows = [json.loads(l) for l in open(path) if l.startswith("{")]
     rows = [r for r in rows if "auto_ms" in r]
+    old = {}
+    if before:
+        old = {(r["graph"], r["N"]): r for r in (json.loads(l) for l in open(before) if l.startswith("{")) if "auto_ms" in r}
     print("# Regret of the auto rules on structured graphs (scripts/regret.py; every C bit-identical to `spmm_kernel_ref`)\n")
     print("Graphs: `hpc_amd/synth.py` `csr_dcsbm_device` (degree-corrected block model with the rows / nonzeros / longest row of the reference's datasets, symmetric: hub rows are hub columns), "
           "order = community (a BFS / RCM / partitioner order), shuffled, degree (hubs first); `-rcm`: a true reverse Cuthill-McKee order (scipy); `-unsorted`: columns in random order inside a row; "
           "`rmat20-unpermuted`; `sbm`: equal degrees, dense diagonal blocks.  `auto` and `best forced` re-timed interleaved; regret = auto / best - 1.\n")
-    print("| graph | rows | nnz | longest row | locality % | kLen | auto ms | best forced ms | regret % | best forced setting | single options that beat auto by > 4 % (time ratio) | auto's resolved setting | settings tried | bit-different settings | auto vs spmm_kernel_ref (differing elements) |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    if old:
+        print(f"`auto ms, round-4 rules`: the same graph and width measured by the same script before any rule was touched (`{os.path.basename(before)}`; another box: +-3 %).\n")
+    print("| graph | rows | nnz | longest row | locality % | kLen | auto ms, round-4 rules | auto ms | best forced ms | regret % | best forced setting | single options that beat auto by > 4 % (time ratio) | auto's resolved setting | settings tried | bit-different settings | auto vs spmm_kernel_ref (differing elements) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     worst = []
     short = {"long_row_threshold": "thr", "col_strips": "strips", "tile_cols": "tile", "medium_row_threshold": "mthr", "segment_overlap": "seg_ov", "hub_overlap": "hub_ov",
              "hub_slice": "slice", "fused_step": "fused", "segment_order": "seg_order"}
@@ -115,13 +120,19 @@ def summarize(path):
                 singles.append(f"{short.get(k, k)}={best_v[1]}: {best_v[0]:.2f}")
         auto_s = (f"thr {a['thr'] if a['thr'] != NONE_THR else 'none'}, strips {a['S']}, tile {a['tile']}, mthr {a['mthr']}, {a['hubs']} hubs, {a['segments']} segments ({a['seg_nnz_pct']} % of nnz), "
                   f"{a['launches']} launch{'es' if a['launches'] != 1 else ''}{', small-step kernel' if a.get('fused') else ''}, front {a.get('front_pct')} %, preprocess {a['preprocess_us']} us")
-        print(f"| {r['graph']} | {r['M']} | {r['nnz']} | {r['max_row']} | {a.get('locality_pct', '')} | {r['N']} | {r['auto_ms']:.4f} | {r['best_ms']:.4f} | {r['regret_pct']:.1f} | "
+        o = old.get((r["graph"], r["N"]))
+        print(f"| {r['graph']} | {r['M']} | {r['nnz']} | {r['max_row']} | {a.get('locality_pct', '')} | {r['N']} | {(str(round(o['auto_ms'], 4)) if o else '-')} | {r['auto_ms']:.4f} | {r['best_ms']:.4f} | {r['regret_pct']:.1f} | "
               f"{fmt(r['best_cfg'])} | {'; '.join(singles) or '-'} | {auto_s} | {r['n_tried']} | {r['n_bitdiff']} | {r.get('auto_bitdiff_vs_spmm_kernel_ref')} |")
         worst.append((r["regret_pct"], r["graph"], r["N"]))
     worst.sort(reverse=True)
     print(f"\nmax regret {worst[0][0]:.1f} % ({worst[0][1]}, kLen {worst[0][2]}); entries above 10 %: {sum(1 for w in worst if w[0] > 10)} of {len(worst)}; "
           f"median {sorted(w[0] for w in worst)[len(worst) // 2]:.1f} %")
     print("\nworst ten: " + "; ".join(f"{g} kLen {n}: {p:.1f} %" for p, g, n in worst[:10]))
+    if old:
+        both = [(o["auto_ms"] / r["auto_ms"]) for r in rows for o in [old.get((r["graph"], r["N"]))] if o]
+        if both:
+            print(f"\nauto, round-4 rules -> now, over the {len(both)} entries measured both times: geometric mean speed-up {float(np.exp(np.mean(np.log(both)))):.3f}, "
+                  f"best {max(both):.2f}x, worst {min(both):.2f}x")
 
 
 def main():
@@ -131,10 +142,11 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-ref", action="store_true", help="skip the comparison with spmm_kernel_ref (bits are still compared with auto's)")
     ap.add_argument("--summarize", default=None)
+    ap.add_argument("--before", default=None, help="with --summarize: the JSONL of the same script from before the rule fixes (adds a column)")
     ap.add_argument("--full-grid-below", type=int, default=8_000_000)
     args = ap.parse_args()
     if args.summarize:
-        summarize(args.summarize)
+        summarize(args.summarize, args.before)
         return
     import torch
     from hpc_amd import CSR, SpMMOpt
