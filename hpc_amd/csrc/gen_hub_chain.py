@@ -23,10 +23,9 @@ The loop is unrolled over the ring's 6 slots = 3 pairs, so that every LDS addres
 
     python3 hpc_amd/csrc/gen_hub_chain.py        (the output is committed; re-run after editing this file)
 
-Registers (fixed, all on the clobber list): B set 0 (a stage's first half) v[32:63], B set 1 (second half) v[64:95]; a values
-of even stages v[96:96+NA-1], of odd stages v[112:112+NA-1] (NA = 4, or 16 with quad_perm); v128 polled count, v129 scratch,
-v130/v131 this lane's B address for slots 0-2 / 3-5, v132/v133 this lane's a address for slots 0-2 / 3-5, v134 address of
-flags[]; s80 stages finished, s81 byte offset of the tail stage's slot, s84 the count `pub` must have reached before the next
+Registers (fixed, all on the clobber list, packed from v16 up: round 5): B set 0 (a stage's first half) v[16:47], B set 1 (second half) v[48:79];
+a values of even stages v[80:80+NA-1], of odd stages v[80+NA:80+2NA-1] (NA = 4, or 16 with quad_perm); then the polled count, a scratch,
+this lane's B address for slots 0-2 / 3-5, this lane's a address for slots 0-2 / 3-5, the address of flags[] (v88 .. v94 with NA = 4); s80 stages finished, s81 byte offset of the tail stage's slot, s84 the count `pub` must have reached before the next
 pair starts fetching, s85 scratch, s86 stages the pair loop covers (nf with bit 0 cleared).
 Operands: %[acc] +v the lane's accumulator | %[bb] v LDS byte address of this lane's column in slot 0 | %[ra] v LDS byte
 address this lane reads slot 0's a values from (a values + 16 (lane & 15); quad_perm: + 16 (lane & 3)) | %[fl] s LDS byte
@@ -39,9 +38,14 @@ import os
 
 ST, LOADERS, NB, CS = 64, 3, 6, 68          # HubCfg: nonzeros per stage, loader waves, ring slots, column stride in floats
 A_MODE = "row"                              # "row": DPP row_newbcast, 1 a read per stage | "quad": DPP quad_perm, 4 a reads per stage
-B = [32, 64]                                # first VGPR of B set 0 (first half of a stage) / 1 (second half)
-A = [96, 112]                               # first VGPR of the a values of even / odd stages
-V_POLL, V_TMP, V_B, V_A, V_FL = 128, 129, (130, 131), (132, 133), 134
+# Round 5: the fixed registers are packed downwards (they were v32 .. v134 with gaps, which alone made spmm_hub<16> -- and the small-step kernel that runs
+# it as one of its roles -- a 135-VGPR, 3-waves-per-SIMD kernel).  Nothing but the names changes.
+B = [16, 48]                                # first VGPR of B set 0 (first half of a stage) / 1 (second half)
+NA = 4 if A_MODE == "row" else 16
+A = [80, 80 + NA]                           # first VGPR of the a values of even / odd stages
+_M = 80 + 2 * NA
+V_POLL, V_TMP, V_B, V_A, V_FL = _M, _M + 1, (_M + 2, _M + 3), (_M + 4, _M + 5), _M + 6
+V_FIRST = B[0]
 DONE_OFF = 4 * LOADERS                      # flags[3]
 
 
@@ -140,7 +144,7 @@ def text(sw):
 
 
 def render():
-    clob = [f"v{i}" for i in range(32, V_FL + 1)] + ["s80", "s81", "s84", "s85", "s86", "scc", "memory"]
+    clob = [f"v{i}" for i in range(V_FIRST, V_FL + 1)] + ["s80", "s81", "s84", "s85", "s86", "scc", "memory"]
     out = ["// GENERATED by gen_hub_chain.py -- do not edit; see that file for the register map and the protocol.\n"]
     for sw in (16, 32, 64):
         out.append(f"#define MI_HUB_CHAIN_SLOT_BYTES_{sw} {slot_bytes(sw)}\n")

@@ -1198,11 +1198,15 @@ void launch_block_items(int slab, int cls, bool wide, const BlockArgs &a, dim3 g
     else { if (wide) launch_block_items_g<1, true, false>(slab, a, grid, s, bt); else launch_block_items_g<1, false, false>(slab, a, grid, s, bt); }
 }
 
-void launch_small_step(int lpr, const SmallStepArgs &a, dim3 grid, hipStream_t s)
+void launch_small_step(int lpr, int deep, const SmallStepArgs &a, dim3 grid, hipStream_t s)
 {
-    // segments 16 gathers deep: 114 - 128 VGPRs, inside the hub role's 135 (32 deep would make the whole kernel a 2-waves-per-SIMD kernel)
+    // segments 16 gathers deep: 114 - 128 VGPRs beside the hub role's 112 (32 deep would make the whole kernel a 2-waves-per-SIMD kernel).  The 8-lane
+    // instance is 3 dwords over 128 and spills them (12 bytes of scratch per lane); "segment_unroll" = 8 selects its 8-deep form, which does not.
     switch (lpr) {
-    case 8: hipLaunchKernelGGL((spmm_small_step<8, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 8:
+        if (deep == 8) hipLaunchKernelGGL((spmm_small_step<8, 8>), grid, dim3(kBlockThreads), 0, s, a);
+        else hipLaunchKernelGGL((spmm_small_step<8, 16>), grid, dim3(kBlockThreads), 0, s, a);
+        break;
     case 16: hipLaunchKernelGGL((spmm_small_step<16, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
     case 32: hipLaunchKernelGGL((spmm_small_step<32, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
     default: hipLaunchKernelGGL((spmm_small_step<64, 16>), grid, dim3(kBlockThreads), 0, s, a); break;
@@ -1346,7 +1350,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
             const int rows_wgs = h->n_rows_for_rows_kernel > 0 ? (int)nblk64 : 0;       // every row may belong to the first two roles (ddi-shaped graphs)
             if (fa.hub_wgs + fa.seg_wgs + rows_wgs == 0) { *launches_out += 0; return MI_SPMM_OK; }
             dim3 fgrid((unsigned)(fa.hub_wgs + fa.seg_wgs + rows_wgs));
-            launch_small_step(lpr, fa, fgrid, s);
+            launch_small_step(lpr, (int)h->segment_unroll, fa, fgrid, s);
             h->last_fused = 1;
             if (record) { h->last_wide = 0; h->last_lpr = lpr; h->last_v = V; }
             *launches_out += 1;

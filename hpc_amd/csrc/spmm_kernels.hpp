@@ -707,9 +707,10 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 // roles of one grid: workgroups [0, hub_wgs) are hub (row, slice) workgroups -- first in the grid, so the longest dependent chain of the step starts first
 // (the hub table is longest-first) --, [hub_wgs, hub_wgs + seg_wgs) take segments (longest first as well), the rest short rows.  No fork, no join, no
 // stream test, one ramp.  Same device functions, same arguments, same arithmetic: same bits.
-// Footprint (make asm, -Rpass-analysis=kernel-resource-usage): the kernel's registers and LDS are the largest role's -- the hub role with 16-column slices
-// (135 VGPRs, 27.7 KB of LDS: 3 waves per SIMD) -- so the rows role runs at 3 waves per SIMD instead of 5 - 8: acceptable only where the step is short and
-// latency-bound anyway, which is the host's rule for using this kernel (mi_spmm.hip: estimated step < 0.2 ms, one column tile, no strips, no blocks).
+// Footprint (make asm, -Rpass-analysis=kernel-resource-usage): the kernel's registers and LDS are the largest role's.  With the chain loop's fixed registers
+// packed from v16 up (gen_hub_chain.py, round 5: they were v32 .. v134, which made the hub role -- and this kernel -- 135 VGPRs, 3 waves per SIMD) the hub role
+// with 16-column slices needs 112 VGPRs and 27.7 KB of LDS, the segment role 16 gathers deep 114 - 128: the kernel is held to 128 (amdgpu_waves_per_eu(4)),
+// FOUR waves per SIMD for every role (rows alone: 5 - 8).  Used where the step is short and latency-bound anyway (mi_spmm.hip: "fused_step" auto).
 struct SmallStepArgs {
     HubArgs h;
     ChunkArgs c;
@@ -718,7 +719,7 @@ struct SmallStepArgs {
 };
 
 template <int LPR, int SEG_UNROLL>
-__global__ __launch_bounds__(kBlockThreads) void spmm_small_step(SmallStepArgs a)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4))) void spmm_small_step(SmallStepArgs a)
 {
     const int b = (int)blockIdx.x;
     if (b < a.hub_wgs) hub_body<16, false, false>(a.h, b);
