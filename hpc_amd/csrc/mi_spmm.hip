@@ -479,6 +479,7 @@ static int plan_col_strips(mi_spmm_handle *h)
     //  once the rows are long: protein- / reddit-community (58 - 60 % local) 0.57 - 0.67 of the time with strips, and a BANDED matrix of 300-700-nonzero rows
     //  (100 % local: a row sits inside one or two strips) 0.54 - 0.69 -- the segment table is sorted by length, so a launch's rows come from all over the band.
     //  The gate is gone: profiles/r05_regret.md.)
+    if (h->col_strips == 0 && h->local_pct >= 95) return MI_SPMM_OK;      // banded / mesh: the rows stay in the rows kernel (medium rule), nothing long is left to strip
     if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz, h->front_pct) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
     if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
     void *d_sv = (char *)h->d_col_bad + 64;            // (the first bytes hold the column-range flag a second plan reads again)
@@ -491,6 +492,9 @@ static int plan_col_strips(mi_spmm_handle *h)
         if ((int64_t)sv.nnz != h->seg_nnz) return MI_SPMM_ESTATE;      // the plan builders' count and the survey's are the same number
     }
     int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz, h->front_pct);
+    // local columns at a narrow B: a long row's nonzeros cluster in one or two strips, the other launches find it empty -- many strips only add launches
+    // (ppa-community kLen 32: 14 strips DOUBLED the step, 4 are neutral; reddit-community kLen 32: 3 - 4 strips 0.88 - 0.91 of the time, 6 the same as none)
+    if (h->col_strips == 0 && h->local_pct >= 50 && h->feat < 128 && S > 4) S = 4;
     if (S > h->num_cols) S = h->num_cols;
     if (S > kMaxColStrips) S = kMaxColStrips;
     if (S < 2) return MI_SPMM_OK;
@@ -1052,7 +1056,7 @@ static int preprocess_plan(mi_spmm_handle *h)
         // hub rows longest first, ties in row order (as the device builder's stable radix sort leaves them)
         std::stable_sort(longs.begin(), longs.end(), [](const LongRow &x, const LongRow &y) { return x.len > y.len; });
         // longest first, stable: counting sort on the length (<= max(long_thr, long_chunk) by construction) -- unless the row order was asked for
-        if (!(h->seg_order == 2 || (h->seg_order == 0 && h->local_pct >= 50 && !h->split_long))) {       // (auto: plan.hpp segment_order_is_rows)
+        if (h->seg_order != 2) {
         int32_t lmax = 0;
         for (const Chunk &c : chunks) lmax = std::max(lmax, c.end - c.beg);
         std::vector<int32_t> start((size_t)lmax + 2, 0);
@@ -1240,7 +1244,12 @@ int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
     (void)ldb;
     if (h->tile_cols > 0) return (int)h->tile_cols;
     if (h->local_pct < 0 || h->local_pct >= 95) return 256;
-    if (h->local_pct >= 50) return N >= 256 ? 128 : 256;
+    if (h->local_pct >= 50) {
+        if (N < 256) return 256;
+        // (rows of a handful of nonzeros over a B far beyond the Infinity Cache -- youtube-, am-, wikikg2-community at N = 256: 0.91 - 0.94 with the whole wave)
+        const int64_t mean_l = h->num_v > 0 ? h->nnz / h->num_v : 0;
+        return (mean_l < 8 && 4.0 * (double)h->num_cols * (double)N > 256.0 * 1048576.0) ? 256 : 128;
+    }
     const int64_t mean = h->num_v > 0 ? h->nnz / h->num_v : 0;
     const bool hubs = (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1);
     // (... except two tiles of 64 at N = 128 when the hubs come first in the vertex order: their B rows are the hot set, and half-width rows of it fit L2 --
@@ -1323,11 +1332,11 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         const bool eligible = vec4 && !wide && col_tiles == 1 && launch_blocks_here && N == full.N && h->n_strips <= 1 && !h->split_long && h->n_blk_groups == 0 &&
                               bt == kBlockThreads && pol == kPolNtStore && (h->n_long > 0 || h->n_chunks > 0) &&
                               (int64_t)((full.N + 15) / 16) * h->n_long + (int64_t)h->n_chunks + nblk64 < (int64_t)INT32_MAX;
-        // auto: the step's bytes take under 0.12 ms, or its longest row's chain (3.2 ns per nonzero) outlasts them anyway (am-shaped): then the rows role's
+        // auto: the step's bytes take under 0.1 ms, or its longest row's chain (3.2 ns per nonzero) outlasts them anyway (am-shaped): then the rows role's
         // occupancy cannot matter.  (First rule, 0.2 ms: youtube-shaped kLen 32 -- 0.155 ms of bytes, a 75 us chain, 35 K rows workgroups -- lost 6 - 14 %.)
         // (an L2-resident B -- 4 K N <= 6 MiB, ddi-shaped -- moves its bytes three times faster: priced as in plan.hpp resolve_hub_threshold)
         const double t_bytes = step_bytes / (4.0 * (double)h->num_cols * (double)full.N <= 6.0 * 1048576.0 ? 18e12 : 6e12);
-        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < 120e-6 || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
+        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < 100e-6 || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
         h->last_fused = 0;
         if (eligible && want) {
             SmallStepArgs fa{};

@@ -390,10 +390,11 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
                            dim3(kBlockThreads), 0, 0, d_row_ptr, M, thr, clen, seg_cnt, seg_off, slot_off, long_off,
                            unsorted, keys_in, longs_unsorted, lkeys_in);
         PLAN_TRY(hipGetLastError());
-        // segment order: by length (the lane groups of a wave carry similar lengths, the tail is short) -- or, where the columns are local, AS THE ROWS COME:
-        // the segment table sorted by length scatters neighbouring rows (which gather the same B rows) over the chip; in row order they meet in one L2 like the
-        // rows kernel's (round 5: banded long rows 0.55, protein-unsorted 0.89, reddit-community 0.92 of the time; profiles/r05_regret.md).  auto = 0.
-        const bool by_rows = seg_order == 2 || (seg_order == 0 && out->local_pct >= 50 && !split);
+        // segment order: by length (the lane groups of a wave carry similar lengths, the tail is short; auto) or, "segment_order" = 2, as the rows come.  Row
+        // order keeps neighbouring rows -- which gather the same B rows where the columns are local -- together like the rows kernel does; measured on the
+        // structured graphs it is a mixed bag (banded long rows without strips 0.55 of the time, protein-unsorted 0.89; but 1.1 - 1.3x at kLen 32 on every
+        // community order and with strips in force: profiles/r05_regret.md), and what it gains the medium rule gets by keeping the rows in the rows kernel.
+        const bool by_rows = seg_order == 2;
         if (n > 0 && by_rows) PLAN_TRY(hipMemcpyAsync(out->d_chunks, unsorted, n * sizeof(Chunk), hipMemcpyDeviceToDevice, 0));      // row order: as emitted
         else if (n > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, sbytes, keys_in, keys_out, unsorted, out->d_chunks, (int)n, 0, end_bit));
         if (nl > 0) PLAN_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp2, lbytes, lkeys_in, lkeys_out, longs_unsorted, out->d_long, (int)nl, 0, end_bit));

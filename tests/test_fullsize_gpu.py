@@ -129,10 +129,10 @@ def test_c2_power_law_full_size(device, oracle):
     (d_B,) = to_dev(device, B)
     d_ptr, d_idx, d_val, d_C, op = _run_full(device, ptr, idx, vals, d_B, N, M)
     deg = np.diff(ptr)
-    # auto threshold at this size (plan.hpp resolve_hub_threshold): 4096 -- the step hides a 4096-nonzero segment on its side
-    # stream -- so every row of C2 (longest: 4095) is a short row or ONE exact segment; the hub kernel gets its full-size
-    # run below (threshold 2048)
-    assert op.get_option("long_row_threshold") == auto_hub_threshold(M, N, ptr) == 4096
+    # auto threshold at this size (plan.hpp resolve_hub_threshold): the step hides a segment of up to 5 625 nonzeros -- C2's longest row (4 095)
+    # included, so no row needs the hub kernel and the rule returns its largest candidate (round 5; it was 4096, the largest power of two below 5 625:
+    # the same plan here) -- every row of C2 is a short row or ONE exact segment; the hub kernel gets its full-size run below (threshold 2048)
+    assert op.get_option("long_row_threshold") == auto_hub_threshold(M, N, ptr) == 8192
     assert op.get_option("split_long_rows") == 0 and op.get_option("n_partial_slots") == 0
     assert op.get_option("n_hub_rows") == 0 and op.get_option("n_medium_rows") > 0
     assert not torch.isnan(d_C).any()
