@@ -493,8 +493,8 @@ static int plan_col_strips(mi_spmm_handle *h)
     }
     int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz, h->front_pct);
     // local columns at a narrow B: a long row's nonzeros cluster in one or two strips, the other launches find it empty -- many strips only add launches
-    // (ppa-community kLen 32: 14 strips DOUBLED the step, 4 are neutral; reddit-community kLen 32: 3 - 4 strips 0.88 - 0.91 of the time, 6 the same as none)
-    if (h->col_strips == 0 && h->local_pct >= 50 && h->feat < 128 && S > 4) S = 4;
+    // (ppa-community kLen 32: 14 strips DOUBLED the step, 4 are neutral, 2 take a fifth off; reddit- / protein-community kLen 32: 2 - 4 strips 0.88 - 0.95 of the time, 6 the same as none)
+    if (h->col_strips == 0 && h->local_pct >= 50 && h->feat < 128 && S > 2) S = 2;
     if (S > h->num_cols) S = h->num_cols;
     if (S > kMaxColStrips) S = kMaxColStrips;
     if (S < 2) return MI_SPMM_OK;
@@ -564,9 +564,11 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
     // (attempt 2, ADVICE r4: the folded plan surveys the former hub rows for the first time; if one of them has non-ascending columns, or the rule on
     //  the new survey says no strips, the fold has nothing to stand on -- a 10^4-nonzero row would run as ONE unstripped segment chain -- and the plan
     //  with hubs is built again, this time to be kept)
+    int32_t mthr_retry = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         PlanOut po;
-        const int32_t mthr = (int32_t)((h->long_thr == 0 || h->medium_thr < h->long_thr) ? h->medium_thr : h->long_thr);   // 0 = auto
+        const int64_t mthr_want = mthr_retry > 0 ? mthr_retry : h->medium_thr;
+        const int32_t mthr = (int32_t)((h->long_thr == 0 || mthr_want < h->long_thr) ? mthr_want : h->long_thr);   // 0 = auto
         const int rc = build_plan_gpu(h->d_ptr, h->d_idx, M, h->num_cols, h->feat, h->nnz, h->d_blk_flag, d_bad, mthr, (int32_t)h->long_thr,
                                       (int32_t)h->long_chunk, (int32_t)h->split_long, (int32_t)h->seg_order, &h->scratch_a, &h->scratch_b, &po);
         h->d_chunks = po.d_chunks;
@@ -592,6 +594,22 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         const bool fold_hubs = attempt == 0 && h->long_thr_user == 0 && !h->split_long && h->n_strips > 1 && h->n_long > 0 &&
                                (double)h->max_row_nnz * 100e-9 <= 0.5 * step_s;
         const bool unfold = attempt == 1 && h->n_strips <= 1;      // the fold lost its strips: back to the plan with hubs
+        // Local columns, a wide B, segments that hold a quarter of the nonzeros and NO strips for them (columns out of order, or B beyond the rule): what is left
+        // to them is the length-sorted table that scatters neighbours -- the rows kernel takes them instead, up to 1 024 nonzeros (protein-unsorted N = 128 / 256:
+        // 0.83 - 0.85 of the time; profiles/r05_regret.md).  One more plan, on the device: ~0.3 ms of preprocess.
+        const bool keep_rows = attempt == 0 && !fold_hubs && mthr_retry == 0 && h->medium_thr == 0 && !h->split_long && h->local_pct >= 50 && h->local_pct < 95 &&
+                               h->feat >= 128 && M >= 65536 && h->n_strips <= 1 && h->medium_res < 1024 && h->seg_nnz * 4 >= h->nnz;
+        if (keep_rows) {
+            mthr_retry = 1024;
+            if (h->d_chunks) (void)hipFree(h->d_chunks);
+            if (h->d_long) (void)hipFree(h->d_long);
+            if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
+            h->d_chunks = nullptr; h->d_long = nullptr; h->d_blk_groups = nullptr;
+            h->ws_bytes = 0;
+            h->long_thr = h->long_thr_user;      // auto again (0) or the caller's
+            attempt = -1;                        // the loop's ++ makes it 0: the same first attempt, with the other medium threshold
+            continue;
+        }
         if (!fold_hubs && !unfold) break;
         if (h->d_chunks) (void)hipFree(h->d_chunks);
         if (h->d_long) (void)hipFree(h->d_long);

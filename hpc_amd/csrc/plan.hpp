@@ -73,11 +73,12 @@ __host__ __device__ inline int32_t resolve_medium_threshold(int32_t mthr_user, i
     const int32_t old_rule = (int64_t)max_len > 8 * (mean_len > 1 ? mean_len : 1) ? 32 : 64;
     int32_t m = old_rule;
     if (mthr_user > 0) m = mthr_user;
+    else if (M < 65536) { /* too few rows to fill the chip with lane groups: every long row needs the segment kernel's 32 gathers in flight (ddi-shaped) */ }
     else if (local_pct >= 95) m = 1024;       // banded / mesh: every row's B rows are its neighbours' -- the rows kernel keeps all but the longest (banded rows of
                                               // 300 - 700 nonzeros: 0.47 - 0.73 of the time at every width against 64 / 512)
     else if (local_pct >= 50) {
         const double step = ((double)nnz * (4.0 * N + 8.0) + 4.0 * (double)M * N) / 6e12;
-        if (N >= 128) { if (M >= 65536 && step >= 200e-6) m = 512; }
+        if (N >= 128) { if (step >= 200e-6) m = 512; }
         else {
             const int64_t by_mean = 4 * mean_len;
             if (by_mean > m) m = (int32_t)(by_mean < 256 ? by_mean : 256);

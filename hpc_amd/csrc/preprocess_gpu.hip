@@ -40,6 +40,15 @@ __global__ void init_plan_stats(PlanStats *stats)
 // Column locality of a row sample: how many nonzeros sit within `window` columns of their row's own position
 // (row r of M <-> column r*K/M).  Mesh / community / banded structures score ~1, random columns ~2*window/K.
 // Only the column-tile width of the rows kernel depends on it (scheduling, never arithmetic).
+// "near the row's own position": within max(4096, K / 64) columns -- but never more than K / 16 (round 5: a 4 267-column matrix had EVERY column near,
+// 99 % local, and was taken for a banded one)
+static inline int locality_window(int K)
+{
+    int w = K / 64 > 4096 ? K / 64 : 4096;
+    if (w > K / 16) w = K / 16;
+    return w < 1 ? 1 : w;
+}
+
 __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
                                                                 int32_t M, int32_t K, int64_t nnz, int32_t n_samples, int32_t window, PlanStats *stats)
 {
@@ -243,7 +252,7 @@ int sample_columns_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32
     PlanStats *stats = (PlanStats *)d_scratch256;
     hipLaunchKernelGGL(init_plan_stats, dim3(1), dim3(64), 0, 0, stats);
     const int n_samples = M < 8192 ? M : 8192;
-    const int window = K / 64 > 4096 ? K / 64 : 4096;
+    const int window = locality_window(K);
     hipLaunchKernelGGL(sample_locality, dim3((unsigned)((n_samples + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
                        d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
     PLAN_TRY(hipGetLastError());
@@ -297,7 +306,7 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     hipLaunchKernelGGL(row_len_max, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats);
     if (nnz > 0 && K > 0) {
         const int n_samples = M < 8192 ? M : 8192;
-        const int window = K / 64 > 4096 ? K / 64 : 4096;
+        const int window = locality_window(K);
         hipLaunchKernelGGL(sample_locality, dim3((unsigned)((n_samples + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
                            d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
     }
