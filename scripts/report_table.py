@@ -79,7 +79,7 @@ def main():
     skip = set(x for x in args.skip.split(",") if x)
     rows_out = {n: [] for n in lens}
     for name, M, nnz_target, max_deg in DATASETS:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         t = time.time()
         ptr, idx = csr_dataset_shaped(name)
