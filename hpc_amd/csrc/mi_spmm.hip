@@ -1268,6 +1268,8 @@ int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
         const int64_t mean_l = h->num_v > 0 ? h->nnz / h->num_v : 0;
         return (mean_l < 8 && 4.0 * (double)h->num_cols * (double)N > 256.0 * 1048576.0) ? 256 : 128;
     }
+    // an L2-resident B (4 K N <= 6 MiB: ddi-shaped) has no working set to shrink: narrower tiles only re-read A (ddi-community N = 256: 0.76 with the whole wave)
+    if (4.0 * (double)h->num_cols * (double)N <= 6.0 * 1048576.0) return 256;
     const int64_t mean = h->num_v > 0 ? h->nnz / h->num_v : 0;
     const bool hubs = (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1);
     // (... except two tiles of 64 at N = 128 when the hubs come first in the vertex order: their B rows are the hot set, and half-width rows of it fit L2 --
