@@ -480,7 +480,7 @@ static int plan_col_strips(mi_spmm_handle *h)
     //  (100 % local: a row sits inside one or two strips) 0.54 - 0.69 -- the segment table is sorted by length, so a launch's rows come from all over the band.
     //  The gate is gone: profiles/r05_regret.md.)
     if (h->col_strips == 0 && h->local_pct >= 95) return MI_SPMM_OK;      // banded / mesh: the rows stay in the rows kernel (medium rule), nothing long is left to strip
-    if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz, h->front_pct) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
+    if (h->col_strips == 0 && resolve_col_strips(h->num_cols, tile, h->nnz, h->n_chunks, h->nnz, h->front_pct, h->local_pct) < 2) return MI_SPMM_OK;   // cannot pay whatever the survey says
     if (!h->d_col_bad) HIP_TRY(hipMalloc((void **)&h->d_col_bad, 256));
     void *d_sv = (char *)h->d_col_bad + 64;            // (the first bytes hold the column-range flag a second plan reads again)
     SegmentSurvey sv;
@@ -491,7 +491,7 @@ static int plan_col_strips(mi_spmm_handle *h)
         if (sv.unsorted) return MI_SPMM_OK;            // a row whose columns do not ascend cannot be cut by column without changing its order
         if ((int64_t)sv.nnz != h->seg_nnz) return MI_SPMM_ESTATE;      // the plan builders' count and the survey's are the same number
     }
-    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz, h->front_pct);
+    int64_t S = h->col_strips >= 2 ? h->col_strips : resolve_col_strips(h->num_cols, tile, h->seg_nnz, h->n_chunks, h->nnz, h->front_pct, h->local_pct);
     // local columns at a narrow B: a long row's nonzeros cluster in one or two strips, the other launches find it empty -- many strips only add launches
     // (ppa-community kLen 32: 14 strips DOUBLED the step, 4 are neutral, 2 take a fifth off; reddit- / protein-community kLen 32: 2 - 4 strips 0.88 - 0.95 of the time, 6 the same as none)
     if (h->col_strips == 0 && h->local_pct >= 50 && h->feat < 128 && S > 2) S = 2;
@@ -597,10 +597,12 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         // Local columns, a wide B, segments that hold a quarter of the nonzeros and NO strips for them (columns out of order, or B beyond the rule): what is left
         // to them is the length-sorted table that scatters neighbours -- the rows kernel takes them instead, up to 1 024 nonzeros (protein-unsorted N = 128 / 256:
         // 0.83 - 0.85 of the time; profiles/r05_regret.md).  One more plan, on the device: ~0.3 ms of preprocess.
+        // (narrow B: up to 512 -- protein-unsorted kLen 32: 0.85)
+        const int32_t keep_to = h->feat >= 128 ? 1024 : 512;
         const bool keep_rows = attempt == 0 && !fold_hubs && mthr_retry == 0 && h->medium_thr == 0 && !h->split_long && h->local_pct >= 50 && h->local_pct < 95 &&
-                               h->feat >= 128 && M >= 65536 && h->n_strips <= 1 && h->medium_res < 1024 && h->seg_nnz * 4 >= h->nnz;
+                               M >= 65536 && h->n_strips <= 1 && h->medium_res < keep_to && h->seg_nnz * 4 >= h->nnz;
         if (keep_rows) {
-            mthr_retry = 1024;
+            mthr_retry = keep_to;
             if (h->d_chunks) (void)hipFree(h->d_chunks);
             if (h->d_long) (void)hipFree(h->d_long);
             if (h->d_blk_groups) (void)hipFree(h->d_blk_groups);
@@ -1356,7 +1358,10 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         // occupancy cannot matter.  (First rule, 0.2 ms: youtube-shaped kLen 32 -- 0.155 ms of bytes, a 75 us chain, 35 K rows workgroups -- lost 6 - 14 %.)
         // (an L2-resident B -- 4 K N <= 6 MiB, ddi-shaped -- moves its bytes three times faster: priced as in plan.hpp resolve_hub_threshold)
         const double t_bytes = step_bytes / (4.0 * (double)h->num_cols * (double)full.N <= 6.0 * 1048576.0 ? 18e12 : 6e12);
-        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < 100e-6 || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
+        // (local columns: the rows kernel alone is fast and wants its occupancy -- 0.1 ms; columns anywhere: latency-bound whatever the occupancy -- 0.16 ms:
+        //  arxiv-community N = 128 loses 18 % fused, arxiv-rcm gains 16 %; youtube-community kLen 32 loses 14 %, youtube-shuffled gains 11 %)
+        const double t_fused = h->local_pct >= 50 ? 100e-6 : 160e-6;
+        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < t_fused || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
         h->last_fused = 0;
         if (eligible && want) {
             SmallStepArgs fa{};

@@ -146,7 +146,9 @@ int build_col_strips(const Chunk *d_chunks, int32_t n_chunks, const int32_t *d_c
 // orders) puts the hot rows of B into the FIRST strip whatever its width; strips then cannot reach L2 size by the rule above (sub-segments would get too
 // short) and yet four wide ones pay: the first launch gathers the hot rows with nothing cold evicting them, the others stream (rmat20-unpermuted kLen 32 /
 // 128 / 256: 0.88 / 0.95 / 0.87 of the time without, profiles/r05_regret.md).
-inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz, int32_t n_segments, int64_t nnz, int32_t front_pct = 25)
+// local_pct (round 5): where the columns are local a launch's rows already share B rows through L2, and half as many strips do (10 MiB each: reddit-community
+// N = 128 23 -> 11 strips 0.93, protein-community 13 -> 6 strips 0.95 of the time).
+inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz, int32_t n_segments, int64_t nnz, int32_t front_pct = 25, int32_t local_pct = 0)
 {
     // Measured on protein- and reddit-shaped graphs at N = 32 / 128 / 256, strip counts interleaved in one process (profiles/r04_col_strips.txt, sections 2
     // and 9): the best strip holds 4 - 6 MiB of B per column tile (one to one and a half XCD L2s; smaller strips pay more launches and shorter sub-segments
@@ -154,7 +156,7 @@ inline int32_t resolve_col_strips(int64_t K, int32_t tile_cols, int64_t seg_nnz,
     // the segments are not where the step's bytes are.  (A quarter, round 5; it was half: reddit-community at N >= 128 keeps its rows up to 512 nonzeros
     // in the rows kernel -- the medium rule above -- and the longer ones, 40 % of the nonzeros, still gain 0.70 - 0.79 of the step's time from strips.)
     if (n_segments <= 0 || seg_nnz * 4 < nnz) return 1;
-    const double strip_target = 5.0 * 1048576.0;
+    const double strip_target = (local_pct >= 50 ? 10.0 : 5.0) * 1048576.0;
     const double b_bytes = (double)K * 4.0 * (double)tile_cols;
     int64_t s = (int64_t)(b_bytes / strip_target + 0.5);
     const int64_t by_len = seg_nnz / n_segments / 20;                   // sub-segments of >= 20 nonzeros on average
