@@ -99,20 +99,7 @@ struct mi_spmm_handle {
     Scratch scratch_a, scratch_b;
     unsigned int *d_col_bad;   // 256 bytes: the column-range flag
     struct { int32_t off, n; } blk_launch[kMaxPieces][3];   // [pass][0: list items, 1: run items of one piece, 2: shared run items]
-    // "use_graph": the launch set of one (vin, vout, pitches, row range, extra destinations) tuple, captured once into a HIP graph
-    // on a handle-owned stream and replayed by run() with ONE hipGraphLaunch (small graphs: 2-4 launches + a fork/join are
-    // the step).  Captured by preprocess for the buffers it is given (the reference passes run() the same ones,
-    // spmm_cusparse.cu:11-15), re-captured by a run() call with another tuple.
-    int64_t use_graph;
-    hipStream_t gstream;
-    hipStream_t glaunch;        // round 5 experiment: the stream the replay is launched on (tested to run beside the null stream), bracketed by events
-    hipEvent_t ev_gin, ev_gout;
-    hipGraphExec_t gexec;
-    struct GraphKey { const float *vin; float *vout; int64_t ldb, ldc; int32_t r0, r1, n_extra; float *extra[kMaxPeerOut]; } gkey;
     std::vector<int32_t> *hub_rows_sorted;   // host copy of the hub rows, ascending (null: unknown -> every call launches the hub kernel)
-    bool gfailed;               // capture or instantiation failed once for this plan: run() launches directly from then on
-    int32_t glaunches;          // kernel launches inside the captured set
-    int64_t graph_replays, graph_captures;
 };
 
 static const uint32_t kMagic = 0x4d49534du;  // "MISM"
@@ -122,17 +109,8 @@ static const int64_t kMaxLongChunk = 1 << 20;
 
 static bool good(const mi_spmm_handle *h) { return h && h->magic == kMagic; }
 
-static void drop_graph(mi_spmm_handle *h)
-{
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    h->gexec = nullptr;
-    h->gfailed = false;
-    std::memset(&h->gkey, 0, sizeof(h->gkey));
-}
-
 static void free_plan(mi_spmm_handle *h)
 {
-    drop_graph(h);
     if (h->d_chunks) (void)hipFree(h->d_chunks);
     h->n_strips = 1;         // (the strip buffer itself is grow-only: released by destroy)
     h->seg_unsorted = -1;
@@ -598,9 +576,10 @@ static int preprocess_on_gpu(mi_spmm_handle *h, std::chrono::steady_clock::time_
         // to them is the length-sorted table that scatters neighbours -- the rows kernel takes them instead, up to 1 024 nonzeros (protein-unsorted N = 128 / 256:
         // 0.83 - 0.85 of the time; profiles/r05_regret.md).  One more plan, on the device: ~0.3 ms of preprocess.
         // (narrow B: up to 512 -- protein-unsorted kLen 32: 0.85)
+        //  and only on graphs whose ROWS are long, mean degree >= 64: citation-community, mean 10, lost 17 % with it)
         const int32_t keep_to = h->feat >= 128 ? 1024 : 512;
         const bool keep_rows = attempt == 0 && !fold_hubs && mthr_retry == 0 && h->medium_thr == 0 && !h->split_long && h->local_pct >= 50 && h->local_pct < 95 &&
-                               M >= 65536 && h->n_strips <= 1 && h->medium_res < keep_to && h->seg_nnz * 4 >= h->nnz;
+                               M >= 65536 && h->n_strips <= 1 && h->medium_res < keep_to && h->seg_nnz * 4 >= h->nnz && (h->feat >= 128 || h->nnz / M >= 64);
         if (keep_rows) {
             mthr_retry = keep_to;
             if (h->d_chunks) (void)hipFree(h->d_chunks);
@@ -757,10 +736,6 @@ int mi_spmm_destroy(mi_spmm_handle *h)
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->gstream) (void)hipStreamDestroy(h->gstream);
-    if (h->glaunch) (void)hipStreamDestroy(h->glaunch);
-    if (h->ev_gin) (void)hipEventDestroy(h->ev_gin);
-    if (h->ev_gout) (void)hipEventDestroy(h->ev_gout);
     h->magic = 0;
     delete h;
     return MI_SPMM_OK;
@@ -770,8 +745,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
 {
     if (!good(h) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
-    drop_graph(h);     // any option may change the launch set; the next preprocess or run captures it again
-    if (k == "use_graph") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->use_graph = v; }
+    if (k == "use_graph") return MI_SPMM_EUNSUPPORTED;      // removed in round 5 (it only ever lost: profiles/r05_use_graph_experiment.md); a caller captures run() itself
     else if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
@@ -897,10 +871,6 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "pre_table_us") *value = (int64_t)h->phase_us[3];
     else if (k == "pre_upload_us") *value = (int64_t)h->phase_us[4];
     else if (k == "prepared") *value = h->prepared ? 1 : 0;
-    else if (k == "use_graph") *value = h->use_graph;
-    else if (k == "graph_ready") *value = h->gexec ? 1 : 0;
-    else if (k == "graph_replays") *value = h->graph_replays;
-    else if (k == "graph_captures") *value = h->graph_captures;
     else return MI_SPMM_EUNSUPPORTED;
     return MI_SPMM_OK;
 }
@@ -1275,8 +1245,8 @@ int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
     const int64_t mean = h->num_v > 0 ? h->nnz / h->num_v : 0;
     const bool hubs = (int64_t)h->max_row_nnz > 64 * (mean > 1 ? mean : 1);
     // (... except two tiles of 64 at N = 128 when the hubs come first in the vertex order: their B rows are the hot set, and half-width rows of it fit L2 --
-    //  am-degree N = 128: 0.88 of the time with 64; the same graph at N = 256 prefers the whole wave by 0.82)
-    if (mean < 8) return (N <= 128 && N > 64 && hubs && h->front_pct >= 50) ? 64 : 256;
+    //  am-degree N = 128: 0.88 of the time with 64; the same graph at N = 256 prefers the whole wave by 0.82; arxiv-degree, whose B fits the Infinity Cache, 0.89 the other way)
+    if (mean < 8) return (N <= 128 && N > 64 && hubs && h->front_pct >= 50 && 4.0 * (double)h->num_cols * (double)N > 256.0 * 1048576.0) ? 64 : 256;
     if (N >= 256) return 64;
     if (N >= 128 && hubs) return 64;
     return 256;
@@ -1591,39 +1561,6 @@ extern "C" {
 static int launch_set(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc, int32_t row_begin,
                       int32_t row_end, const PeerOut &po, hipStream_t s);
 
-// "use_graph": capture the launch set for `key` on the handle's own stream (side-stream fork/join included: they become
-// branches of the graph) and instantiate it.  Allocates (stream on first use, graph, executable): preprocess does this for
-// the buffers it is given, so that run() on the same buffers stays allocation-free; a run() with other buffers pays it once.
-// A failure is remembered (gfailed) and run() falls back to the plain launches.
-static int capture_launch_set(mi_spmm_handle *h, const mi_spmm_handle::GraphKey &key, const PeerOut &po)
-{
-    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-    if (!h->gstream && hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess) { h->gfailed = true; return MI_SPMM_ENOMEM; }
-    if (h->use_graph == 2 && !h->glaunch) {
-        int ov = 0;
-        if (concurrent_stream(&h->glaunch, 0, &ov) != MI_SPMM_OK || hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming) != hipSuccess) { h->gfailed = true; return MI_SPMM_ENOMEM; }
-    }
-    hipError_t e = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) { (void)hipGetLastError(); h->gfailed = true; return (int)e; }
-    const int rc = launch_set(h, key.vin, key.ldb, key.vout, key.ldc, key.r0, key.r1, po, h->gstream);
-    hipGraph_t g = nullptr;
-    e = hipStreamEndCapture(h->gstream, &g);
-    if (rc != MI_SPMM_OK || e != hipSuccess || !g) {
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        h->gfailed = (rc == MI_SPMM_OK);        // the launch set's own error is the caller's to see; anything else: fall back for good
-        return rc != MI_SPMM_OK ? rc : (e != hipSuccess ? (int)e : MI_SPMM_ENOMEM);
-    }
-    e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { (void)hipGetLastError(); h->gexec = nullptr; h->gfailed = true; return (int)e; }
-    h->gkey = key;
-    h->glaunches = h->last_launches;
-    ++h->graph_captures;
-    return MI_SPMM_OK;
-}
-
 int mi_spmm_run_rows(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d_vout, int64_t ldc,
                      int32_t row_begin, int32_t row_end, void *stream)
 {
@@ -1648,35 +1585,6 @@ int mi_spmm_run_rows_multi(mi_spmm_handle *h, const float *d_vin, int64_t ldb, f
     if (!d_vout || ldc < N || ldb < N) return MI_SPMM_EINVAL;
     if (!d_vin && h->nnz > 0) return MI_SPMM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (h->use_graph && !h->gfailed) {
-        // a caller that is itself capturing (its own graph around run()) gets the plain launches: they are capturable as they are
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (s != nullptr && hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
-        if (st == hipStreamCaptureStatusNone) {
-            mi_spmm_handle::GraphKey key;
-            std::memset(&key, 0, sizeof(key));
-            key.vin = d_vin; key.vout = d_vout; key.ldb = ldb; key.ldc = ldc; key.r0 = row_begin; key.r1 = row_end; key.n_extra = n_extra;
-            for (int q = 0; q < n_extra; ++q) key.extra[q] = d_extra[q];
-            if (!h->gexec || std::memcmp(&key, &h->gkey, sizeof(key)) != 0) {
-                const int crc = capture_launch_set(h, key, po);
-                if (crc != MI_SPMM_OK && !h->gfailed) return crc;      // an argument error of the launch set itself
-            }
-            if (h->gexec) {
-                if (h->use_graph == 2 && h->glaunch) {
-                    // the replay on a handle-owned stream whose queue was tested to run beside the null stream's, ordered into the caller's stream by two events
-                    HIP_TRY(hipEventRecord(h->ev_gin, s));
-                    HIP_TRY(hipStreamWaitEvent(h->glaunch, h->ev_gin, 0));
-                    HIP_TRY(hipGraphLaunch(h->gexec, h->glaunch));
-                    HIP_TRY(hipEventRecord(h->ev_gout, h->glaunch));
-                    HIP_TRY(hipStreamWaitEvent(s, h->ev_gout, 0));
-                } else
-                HIP_TRY(hipGraphLaunch(h->gexec, s));
-                ++h->graph_replays;
-                h->last_launches = h->glaunches;
-                return MI_SPMM_OK;
-            }
-        }
-    }
     return launch_set(h, d_vin, ldb, d_vout, ldc, row_begin, row_end, po, s);
 }
 
@@ -1721,16 +1629,6 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     // the reference zeroes vout here (spmm_opt.cu:67-68) because its kernel accumulates; ours overwrites, so vout is left alone
     const int rc = preprocess_plan(h);
     if (rc != MI_SPMM_OK) return rc;
-    if (h->use_graph && d_vout && (d_vin || h->nnz == 0) && h->num_v > 0 && h->feat > 0) {
-        // the buffers run() will be given (spmm_cusparse.cu:11-15 binds them at preprocess as well): capture now, replay later
-        mi_spmm_handle::GraphKey key;
-        std::memset(&key, 0, sizeof(key));
-        key.vin = d_vin; key.vout = d_vout; key.ldb = h->feat; key.ldc = h->feat; key.r0 = 0; key.r1 = h->num_v;
-        PeerOut po;
-        std::memset(&po, 0, sizeof(po));
-        (void)capture_launch_set(h, key, po);       // a failure leaves run() on the plain launches (or re-capturing)
-        HIP_TRY(hipDeviceSynchronize());
-    }
     return MI_SPMM_OK;
 }
 

@@ -159,13 +159,9 @@ const char *mi_spmm_strerror(int code);
  *                         block groups, default cache policy.  auto: only steps whose bytes take under 0.2 ms at 6 TB/s (there the launch
  *                         boundaries are a third of the step; the rows role runs at the hub role's footprint, 3 waves per SIMD).  1: whenever
  *                         eligible.  Same device functions, same arithmetic: same bits.  Read-only "fused_step_in_force": the last run used it
- *   "use_graph"           0 (default) / 1: the step's launch set (2-4 kernels plus the side streams' fork and join) is captured once
- *                         into a HIP graph on a handle-owned stream and run() replays it with ONE hipGraphLaunch on the caller's
- *                         stream -- for steps of tens of microseconds (small graphs) the launches are the step.  preprocess captures
- *                         for the vin / vout it is given (the reference hands run() the same buffers, test_spmm.cu:35-40), so run() on
- *                         them still allocates nothing; a run call with other buffers, pitches, row range or extra destinations
- *                         re-captures once (that call allocates).  A caller that is itself capturing gets the plain launches.
- *                         Same kernels, same arguments: same bits.  Read-only: "graph_ready", "graph_captures", "graph_replays"
+ *   ("use_graph", round 4 -- the handle capturing its own launch set into a HIP graph and replaying it -- was removed in round 5: it lost on every graph,
+ *    launched on the caller's stream or on a tested stream of its own, profiles/r05_use_graph_experiment.md; the key answers MI_SPMM_EUNSUPPORTED.  run()
+ *    allocates nothing and synchronises nothing, so a caller can still capture it into a graph of its own: test_run_is_graph_capturable_and_stream_ordered.)
  *   "rows_per_block"      rows handled by one workgroup (0 = auto: one row per lane group)
  *   "block_threads"       workgroup size of the pipelined rows kernel (64, 128, 256)
  *   "segment_unroll"      B-row gathers in flight per lane group in the segment kernel: 8, 16, 32; 0 (default) = auto: 32, and 16 for the

@@ -67,7 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--lens", default="32,256")
-    ap.add_argument("--skip", default="", help="debugging: comma list of graph,vendor,student (columns left out; their cells read nan)")
+    ap.add_argument("--skip", default="", help="debugging: comma list of vendor,student (columns left out; their cells read nan)")
     args = ap.parse_args()
     import torch
     from hpc_amd import CSR, SpMMOpt, synth, valid
@@ -96,21 +96,7 @@ def main():
             ours = SpMMOpt(g, N)
             ours.preprocess(d_B, d_C)
             t_ours = timed(lambda: ours.run(d_B, d_C), 3, 10)
-            # the same step replayed from the handle's HIP graph ("use_graph" = 1: one hipGraphLaunch instead of 2-4 launches + fork/join)
-            t_graph, same, t_graph2 = float("nan"), True, float("nan")
-            if "graph" not in skip:
-                for mode in (1, 2):     # 1: hipGraphLaunch on the caller's stream; 2 (round 5): on a handle-owned tested stream, ordered into the caller's by two events
-                    d_G = torch.full((M, N), float("nan"), device=dev)
-                    ours_g = SpMMOpt(g, N)
-                    ours_g.set_option("use_graph", mode)
-                    ours_g.preprocess(d_B, d_G)
-                    tg = timed(lambda: ours_g.run(d_B, d_G), 3, 10)
-                    same = same and bool(torch.equal(d_G.view(torch.int32), d_C.view(torch.int32))) and ours_g.get_option("graph_replays") == 13
-                    if mode == 1:
-                        t_graph = tg
-                    else:
-                        t_graph2 = tg
-                    del ours_g, d_G
+            t_graph, same, t_graph2 = float("nan"), True, float("nan")      # (columns of the round-4 "use_graph" option: removed, profiles/r05_use_graph_experiment.md)
             vend, t_vend, ok = None, float("nan"), True
             if "vendor" not in skip:
                 vend = SpMMRocSparse(g, N)
@@ -133,10 +119,10 @@ def main():
     print("# Reference-style report table on MI355X (dataset-shaped synthetic graphs; see scripts/report_table.py)\n")
     for N in lens:
         print(f"### `kLen = {N}`\n")
-        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | column strips of the segments | ours with use_graph = 1 (same bits?) | saved by the graph (us) | use_graph = 2: replay on a tested stream | saved (us) | floor (us) | time / floor | preprocess (us) |")
-        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+        print("| Dataset (shape of) | rows | nnz | max deg | vendor (rocSPARSE) time | opt (ours) time | speedup | student kernel (hipcc) time | ours vs student | validation vs vendor | rows summed out of stored order | hub rows (stored order, hub kernel) / threshold | launches per step | column strips of the segments | floor (us) | time / floor | preprocess (us) |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
         for r in rows_out[N]:
-            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[16] if r[16] > 1 else '-'} | {r[13]:.6g} ({'same' if r[14] else 'DIFFERENT'}) | {(r[5] - r[13]) * 1e6:.1f} | {r[17]:.6g} | {(r[5] - r[17]) * 1e6:.1f} | {r[18] * 1e6:.1f} | {r[5] / r[18]:.2f} | {r[19]} |")
+            print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.6g} | {r[5]:.6g} | {r[6]:.2f} | {r[7]:.6g} | {r[8]:.2f} | {'OK' if r[9] else 'FAIL'} | {0 if r[11] == 0 else 'SPLIT'} | {r[10]} / {r[12]} | {r[15]} | {r[16] if r[16] > 1 else '-'} | {r[18] * 1e6:.1f} | {r[5] / r[18]:.2f} | {r[19]} |")
         sp = [r[6] for r in rows_out[N]]
         if sp:
             print(f"\nspeed-up over the vendor library: min {min(sp):.2f}, geometric mean {float(np.exp(np.mean(np.log(sp)))):.2f}, max {max(sp):.2f} "

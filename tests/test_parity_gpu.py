@@ -993,84 +993,21 @@ def test_every_handle_gets_a_hub_stream_that_overlaps(device, oracle):
     assert _lib.load().mi_spmm_stream_create_concurrent(C.byref(s), 1, C.byref(ov)) == 0 and s.value and ov.value == 1
 
 
-@pytest.mark.parametrize("overlap", [0, 2])
-def test_use_graph_replays_the_captured_launch_set(device, oracle, overlap):
-    """ "use_graph" = 1: preprocess captures the step's launch set (hub + segments + rows, side-stream fork / join included)
-    into a HIP graph on a handle-owned stream, for the buffers it is handed -- the reference hands run() the same ones
-    (test_spmm.cu:35-40) -- and run() replays it with one hipGraphLaunch on the caller's stream: same bits, overwrite and
-    idempotent as before, stream-ordered, no allocation in run() for those buffers.  Other buffers, pitches or row ranges
-    re-capture once; a caller that is itself capturing gets the plain (capturable) launches."""
+def test_use_graph_option_is_gone(device):
+    """Round 4's "use_graph" (the handle replaying its own captured launch set) only ever lost -- on the caller's stream and, round 5, on a tested stream of
+    its own (profiles/r05_use_graph_experiment.md) -- and was removed: the key is refused.  A caller's own capture of run() is covered by
+    test_run_is_graph_capturable_and_stream_ordered and test_column_strips_inside_a_captured_graph."""
     import torch
-    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd import CSR, SpMMOpt, MiSpmmError
 
-    ptr, idx = synth.csr_powerlaw(6000, 24.0, 2000, seed=3)
-    vals = synth.normal_f32(idx.size, 4)
-    B = synth.normal_f32(6000 * 64, 5).reshape(6000, 64)
-    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
-    d_C = torch.full((6000, 64), float("nan"), device=device)
-    op = SpMMOpt(CSR(6000, idx.size, d_ptr, d_idx, d_val), 64)
-    op.set_option("long_row_threshold", 512)
-    op.set_option("hub_overlap", overlap)
-    op.set_option("segment_overlap", 1 if overlap == 2 else 0)      # both side streams become branches of the graph
-    op.set_option("use_graph", 1)
-    assert op.get_option("use_graph") == 1 and op.get_option("graph_ready") == 0
-    op.preprocess(d_B, d_C)
-    assert op.get_option("graph_ready") == 1 and op.get_option("graph_captures") == 1 and op.get_option("graph_replays") == 0
-    exp = expected(oracle, ptr, idx, vals, B)
-    for rep in range(3):                                        # null stream, as the reference runs it
-        d_C.fill_(float("nan"))
-        op.run(d_B, d_C)
-        torch.cuda.synchronize()
-        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
-    assert op.get_option("graph_replays") == 3 and op.get_option("graph_captures") == 1 and op.get_option("n_launches") == 3
-    # stream order on a caller's stream: fill -> run -> scale must happen in that order, all on `side`
-    side = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(side):
-        d_C.fill_(float("nan"))
-        op.run(d_B, d_C)
-        d_C.mul_(2.0)
-    side.synchronize()
-    assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
-    assert op.get_option("graph_replays") == 4 and op.get_option("graph_captures") == 1
-    # new B CONTENTS, same buffers: the graph holds pointers, not values
-    d_B.mul_(2.0)
-    op.run(d_B, d_C)
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(d_C.cpu().numpy()), bits((exp * 2).astype(np.float32)))
-    d_B.mul_(0.5)
-    # another output buffer: one re-capture, then replays
-    d_C2 = torch.full((6000, 64), float("nan"), device=device)
-    op.run(d_B, d_C2)
-    op.run(d_B, d_C2)
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(d_C2.cpu().numpy()), bits(exp)) and op.get_option("graph_captures") == 2 and op.get_option("graph_replays") == 7
-    # a row range (the multi-GPU driver's panels) and pitched buffers: their own tuple
-    d_Cw = torch.full((6000, 80), float("nan"), device=device)
-    op.run_rows(d_B, 64, d_Cw, 80, 1000, 5000)
-    torch.cuda.synchronize()
-    got = d_Cw.cpu().numpy()
-    assert np.array_equal(bits(got[1000:5000, :64]), bits(exp[1000:5000])) and np.isnan(got[:1000]).all() and np.isnan(got[5000:]).all() and np.isnan(got[:, 64:]).all()
-    assert op.get_option("graph_captures") == 3
-    # the caller captures run() into a graph of its own: plain launches, no nested graph launch
-    replays = op.get_option("graph_replays")
-    g = torch.cuda.CUDAGraph()
-    d_C.fill_(float("nan"))
-    with torch.cuda.graph(g):
-        op.run(d_B, d_C)
-    d_C.fill_(float("nan"))
-    g.replay()
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)) and op.get_option("graph_replays") == replays
-    # an option change drops the graph; the plain path still works; preprocess captures again
-    op.set_option("use_graph", 0)
-    assert op.get_option("graph_ready") == 0
-    d_C.fill_(float("nan"))
-    op.run(d_B, d_C)
-    torch.cuda.synchronize()
-    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)) and op.get_option("graph_replays") == replays
-    # a graph-less handle and a graphed one agree on a small plain graph too (rows kernel only)
-    C1, op1 = run_spmm(device, ptr[:101], idx[:ptr[100]], vals[:ptr[100]], B, options={"use_graph": 1})
-    assert np.array_equal(bits(C1), bits(oracle.spmm_omp(ptr[:101], idx[:ptr[100]], vals[:ptr[100]], B))) and op1.get_option("graph_replays") == 1
+    ptr = torch.zeros(2, dtype=torch.int32, device=device)
+    op = SpMMOpt(CSR(1, 0, ptr, torch.zeros(0, dtype=torch.int32, device=device), torch.zeros(0, dtype=torch.float32, device=device)), 4)
+    with pytest.raises(MiSpmmError) as e:
+        op.set_option("use_graph", 1)
+    assert e.value.code == -5
+    for key in ("use_graph", "graph_ready", "graph_replays"):
+        with pytest.raises(MiSpmmError):
+            op.get_option(key)
 
 
 def test_negative_zero_accumulators_survive_padded_batches(device, oracle):
@@ -1650,8 +1587,8 @@ def test_column_strips_fold_hubs_whose_chains_hide_inside_the_strips(device, ora
 
 @pytest.mark.parametrize("overlap", [0, 2])
 def test_column_strips_inside_a_captured_graph(device, oracle, overlap):
-    """The strip launches are ordinary stream-ordered launches: captured into the handle's HIP graph ("use_graph") and into a caller's own
-    capture they replay to the same bits, with the segment kernel on the caller's stream or on its side stream."""
+    """The strip launches are ordinary stream-ordered launches: captured into a caller's own HIP graph they replay to the same bits, with the segment
+    kernel on the caller's stream or on its side stream."""
     import torch
     from hpc_amd import CSR, SpMMOpt
 
@@ -1663,19 +1600,13 @@ def test_column_strips_inside_a_captured_graph(device, oracle, overlap):
     d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
     d_C = torch.full((M, N), float("nan"), device=device)
     op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N, num_cols=K)
-    for k, v in {"col_strips": 4, "long_row_threshold": 1024, "medium_row_threshold": 32, "hub_overlap": overlap, "segment_overlap": 1 if overlap == 2 else 0, "use_graph": 1}.items():
+    for k, v in {"col_strips": 4, "long_row_threshold": 1024, "medium_row_threshold": 32, "hub_overlap": overlap, "segment_overlap": 1 if overlap == 2 else 0}.items():
         op.set_option(k, v)
     op.preprocess(d_B, d_C)
-    assert op.get_option("n_col_strips") == 4 and op.get_option("graph_ready") == 1 and op.get_option("n_hub_rows") == 2
-    for rep in range(3):
-        d_C.fill_(float("nan"))
-        op.run(d_B, d_C)
-        torch.cuda.synchronize()
-        assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
-    assert op.get_option("graph_replays") == 3 and op.get_option("n_launches") == 5        # hub kernel + 4 strips (no row is short enough for the rows kernel)
-    # a caller's own capture of the plain launches
-    op.set_option("use_graph", 0)
-    op.preprocess(d_B, d_C)
+    assert op.get_option("n_col_strips") == 4 and op.get_option("n_hub_rows") == 2
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp)) and op.get_option("n_launches") == 5        # hub kernel + 4 strips (no row is short enough for the rows kernel)
     s = torch.cuda.Stream(device=device)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s):
