@@ -91,8 +91,17 @@ class Timer:
 
 
 def summarize(path, before=None):
-    rows = [json.loads(l) for l in open(path) if l.startswith("{")]
-    rows = [r for r in rows if "auto_ms" in r]
+    # several files, comma separated: a later file's entry for the same (graph, kLen) replaces an earlier one (a re-run of the graphs a last rule touched)
+    merged, n_files = {}, 0
+    for one in path.split(","):
+        n_files += 1
+        for l in open(one):
+            if l.startswith("{"):
+                r = json.loads(l)
+                if "auto_ms" in r:
+                    r["_file"] = os.path.basename(one)
+                    merged[(r["graph"], r["N"])] = r
+    rows = list(merged.values())
     old = {}
     if before:
         old = {(r["graph"], r["N"]): r for r in (json.loads(l) for l in open(before) if l.startswith("{")) if "auto_ms" in r}
@@ -125,6 +134,9 @@ def summarize(path, before=None):
               f"{fmt(r['best_cfg'])} | {'; '.join(singles) or '-'} | {auto_s} | {r['n_tried']} | {r['n_bitdiff']} | {r.get('auto_bitdiff_vs_spmm_kernel_ref')} |")
         worst.append((r["regret_pct"], r["graph"], r["N"]))
     worst.sort(reverse=True)
+    if n_files > 1:
+        later = sorted({(r["graph"]) for r in rows if r["_file"] != os.path.basename(path.split(",")[0])})
+        print(f"\nEntries from a later run (the rules' last touches re-measured on the graphs they concern: {', '.join(later)}): {', '.join(os.path.basename(x) for x in path.split(',')[1:])}.")
     print(f"\nmax regret {worst[0][0]:.1f} % ({worst[0][1]}, kLen {worst[0][2]}); entries above 10 %: {sum(1 for w in worst if w[0] > 10)} of {len(worst)}; "
           f"median {sorted(w[0] for w in worst)[len(worst) // 2]:.1f} %")
     print("\nworst ten: " + "; ".join(f"{g} kLen {n}: {p:.1f} %" for p, g, n in worst[:10]))
