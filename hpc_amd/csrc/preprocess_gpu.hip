@@ -49,22 +49,24 @@ static inline int locality_window(int K)
     return w < 1 ? 1 : w;
 }
 
+// (round 5: one WAVE per sampled row, lanes striding its columns -- one thread per row walked a 500-nonzero row serially: 142 us of the LONG_ROWS preprocess)
 __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
                                                                 int32_t M, int32_t K, int64_t nnz, int32_t n_samples, int32_t window, PlanStats *stats)
 {
-    const int i = (int)(blockIdx.x * (unsigned)kBlockThreads + threadIdx.x);
+    const int i = (int)((blockIdx.x * (unsigned)kBlockThreads + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
     int near = 0, tot = 0, front = 0;
     if (i < n_samples) {
         const int r = (int)((int64_t)i * M / n_samples);
         const int beg = row_ptr[r], end = row_ptr[r + 1];
         const int64_t home = (int64_t)r * K / (M > 0 ? M : 1);
         if (beg >= 0 && end <= nnz && end - beg <= 4096) {     // runs before row_ptr has been validated; hubs say nothing about locality
-            for (int k = beg; k < end; ++k) {
-                const int64_t d = (int64_t)col_idx[k] - home;
+            for (int k = beg + lane; k < end; k += 64) {
+                const int32_t c = col_idx[k];
+                const int64_t d = (int64_t)c - home;
                 near += (d <= window && d >= -(int64_t)window) ? 1 : 0;
-                front += col_idx[k] < K / 4 ? 1 : 0;
+                front += c < K / 4 ? 1 : 0;
             }
-            tot = end - beg;
+            tot = lane == 0 ? end - beg : 0;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -72,34 +74,53 @@ __global__ __launch_bounds__(kBlockThreads) void sample_locality(const int32_t *
         tot += __shfl_down(tot, off, 64);
         front += __shfl_down(front, off, 64);
     }
-    if ((threadIdx.x & 63) == 0 && tot > 0) {
-        atomicAdd(&stats->near, near);
-        atomicAdd(&stats->sampled, tot);
-        atomicAdd(&stats->front, front);
+    // one atomic triple per WORKGROUP (four sampled rows): through LDS
+    __shared__ int acc[3];
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0 && tot > 0) {
+        atomicAdd(&acc[0], near);
+        atomicAdd(&acc[1], tot);
+        atomicAdd(&acc[2], front);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && acc[1] > 0) {
+        atomicAdd(&stats->near, acc[0]);
+        atomicAdd(&stats->sampled, acc[1]);
+        atomicAdd(&stats->front, acc[2]);
     }
 }
 
-// Longest row, ahead of the classification: the auto medium threshold depends on it.
+// Longest row and the row-length histogram, ahead of the classification (the auto thresholds depend on them).  Grid-stride: a thread accumulates over its
+// rows, a wave reduces once at the end -- one same-address atomic pair per wave and histogram level in all (round 5; one per wave of 64 ROWS was 73 us of
+// the LONG_ROWS preprocess: 2 048 waves x 2 levels on one address each).
 __global__ __launch_bounds__(kBlockThreads) void row_len_max(const int32_t *__restrict__ row_ptr, int32_t M, PlanStats *stats)
 {
-    const int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
-    const int len = (r < M) ? row_ptr[r + 1] - row_ptr[r] : 0;
-    // rows above 256, 512, ... 8192 nonzeros: count and content, one pair of atomics per wave and threshold that has any
+    unsigned cnt[kHistN];
+    unsigned long long part[kHistN];
+#pragma unroll
+    for (int i = 0; i < kHistN; ++i) { cnt[i] = 0; part[i] = 0ull; }
+    int m = 0;
+    for (int64_t r = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x; r < M; r += (int64_t)gridDim.x * kBlockThreads) {
+        const int len = row_ptr[r + 1] - row_ptr[r];
+        m = max(m, len);
+#pragma unroll
+        for (int i = 0; i < kHistN; ++i)
+            if (len > hist_threshold(i)) { ++cnt[i]; part[i] += (unsigned long long)len; }
+    }
 #pragma unroll
     for (int i = 0; i < kHistN; ++i) {
-        const bool above = len > hist_threshold(i);
-        const unsigned long long mask = __ballot(above);
-        if (mask == 0) break;                              // wave-uniform; a longer threshold has none either
-        unsigned long long part = above ? (unsigned long long)len : 0ull;
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if (__ballot(cnt[i] != 0) == 0) break;                 // wave-uniform; a longer threshold has none either
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt[i] += __shfl_down(cnt[i], off, 64);
+            part[i] += __shfl_down(part[i], off, 64);
+        }
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats->hist.cnt[i], (uint32_t)__builtin_popcountll(mask));
-            atomicAdd(&stats->hist.nnz[i], part);
+            atomicAdd(&stats->hist.cnt[i], cnt[i]);
+            atomicAdd(&stats->hist.nnz[i], part[i]);
         }
     }
-    int m = len;
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
-    // one same-address atomic per wave was most of this kernel's time (16 K waves): skip it unless it can raise the max
     if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&stats->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(&stats->max_len, m);
 }
@@ -253,7 +274,7 @@ int sample_columns_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32
     hipLaunchKernelGGL(init_plan_stats, dim3(1), dim3(64), 0, 0, stats);
     const int n_samples = M < 8192 ? M : 8192;
     const int window = locality_window(K);
-    hipLaunchKernelGGL(sample_locality, dim3((unsigned)((n_samples + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
+    hipLaunchKernelGGL(sample_locality, dim3((unsigned)(((size_t)n_samples * 64 + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
                        d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
     PLAN_TRY(hipGetLastError());
     PlanStats host;
@@ -303,11 +324,11 @@ int build_plan_gpu(const int32_t *d_row_ptr, const int32_t *d_col_idx, int32_t M
     int32_t *seg_cnt = cnt, *slot_cnt = seg_cnt + n1, *long_cnt = slot_cnt + n1;
     int32_t *seg_off = off, *slot_off = seg_off + n1, *long_off = slot_off + n1;
     const unsigned grid = (unsigned)((n1 + kBlockThreads - 1) / kBlockThreads);
-    hipLaunchKernelGGL(row_len_max, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats);
+    hipLaunchKernelGGL(row_len_max, dim3(grid < 1024u ? grid : 1024u), dim3(kBlockThreads), 0, 0, d_row_ptr, M, stats);
     if (nnz > 0 && K > 0) {
         const int n_samples = M < 8192 ? M : 8192;
         const int window = locality_window(K);
-        hipLaunchKernelGGL(sample_locality, dim3((unsigned)((n_samples + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
+        hipLaunchKernelGGL(sample_locality, dim3((unsigned)(((size_t)n_samples * 64 + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0, 0,
                            d_row_ptr, d_col_idx, M, K, nnz, n_samples, window, stats);
     }
     hipLaunchKernelGGL(classify_rows, dim3(grid), dim3(kBlockThreads), 0, 0, d_row_ptr, M, d_blk_flag, mthr,
