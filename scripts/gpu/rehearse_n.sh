@@ -5,14 +5,14 @@ set -o pipefail
 n=${1:-4}; steps=${2:-10}; warm=${3:-3}
 out=gpurun_out; mkdir -p $out
 MI_SPMM_WATCHDOG_S=${MI_SPMM_WATCHDOG_S:-60} MI_SPMM_SHARE_GPU=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29517 \
-  bench.py --gpus $n --steps $steps --warmup $warm > $out/r04_launch_line_rehearsal_n$n.json 2> $out/r04_launch_line_rehearsal_n$n.err
+  bench.py --gpus $n --steps $steps --warmup $warm > $out/${TAG:-r05}_launch_line_rehearsal_n$n.json 2> $out/${TAG:-r05}_launch_line_rehearsal_n$n.err
 rc=$?
-echo "rc=$rc"; grep "\[bench\]" $out/r04_launch_line_rehearsal_n$n.err | tail -30
-python - "$out/r04_launch_line_rehearsal_n$n.json" <<'PY'
+echo "rc=$rc"; grep "\[bench\]" $out/${TAG:-r05}_launch_line_rehearsal_n$n.err | tail -30
+python - "$out/${TAG:-r05}_launch_line_rehearsal_n$n.json" <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
-    print({k: d.get(k) for k in ("n_gpus", "ms_per_step", "value", "speedup_vs_one_gpu", "rehearsal")}, d.get("exchange_selection"))
+    print({k: d.get(k) for k in ("n_gpus", "ms_per_step", "value", "speedup_vs_one_gpu", "rehearsal")}, d.get("exchange_selection"), (d.get("multi_gpu_breakdown") or {}).get("links"))
 except Exception as e:
     print("no line:", e)
 PY
