@@ -41,10 +41,14 @@ def _separate_kernels_unless_a_test_asks(request):
         return
     orig = _spmm.SpMMOpt.__init__
 
+    # MI_SPMM_TEST_FUSED=1 (scripts/gpu/soak.sh FUSED=1): the other way round -- every eligible step of the fuzz tests goes through the small-step kernel
+    # (only the tests that check bits, not launch counts, make sense that way)
+    default = 1 if os.environ.get("MI_SPMM_TEST_FUSED") == "1" else 0
+
     def init(self, *a, **k):
         orig(self, *a, **k)
         try:
-            self.set_option("fused_step", 0)
+            self.set_option("fused_step", default)
         except Exception:
             pass
 
