@@ -885,7 +885,9 @@ def also_configs(args, dev, c1_tensors, M):
             cyc = ms * 1e-3 * HUB_CLOCK_HZ / max(1, longest)
             gbs = model["bytes_alg"] / (ms * 1e-3) / 1e9
             roof = {"bound": "chain", "bound_detail": "the longest row's stored-order fma chain (spmm_ref.cu:10-14 allows no other order): floor ~5 cycles per nonzero "
-                    "of that row at 2.4 GHz; achieved = step time x clock / longest row", "kernel": "mi::spmm_hub", "achieved": round(cyc, 2), "peak": 5.0,
+                    "of that row at 2.4 GHz; achieved = step time x clock / longest row",
+                    "kernel": "mi::spmm_hub" + (" (as the hub role of mi::spmm_small_step: the step is one launch)" if op.get_option("fused_step_in_force") else ""),
+                    "achieved": round(cyc, 2), "peak": 5.0,
                     "unit": "cycles per nonzero of the longest row (lower is better; frac = floor / achieved)", "frac": round(5.0 / cyc, 4),
                     "cycles_per_nonzero": round(cyc, 2), "floor_cycles": 5.0, "longest_row": int(longest), "ns_per_nonzero": round(ms * 1e6 / max(1, longest), 3),
                     "chain_floor_ms": round(5.0 * longest / HUB_CLOCK_HZ * 1e3, 4), "bytes_alg": model["bytes_alg"], "bytes_min": model["bytes_min"],
