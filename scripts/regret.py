@@ -73,6 +73,33 @@ def graph_list(quick):
     return g
 
 
+def holdout_list():
+    """Graphs NO rule was fitted on (--holdout): other orders of the same dataset shapes, the largest shape, a weaker block model, a smaller R-MAT, a wider
+    band -- the check that the rules of plan.hpp were fitted to structure, not to the 25 graphs of graph_list()."""
+    from hpc_amd import synth
+
+    def ds(name, **kw):
+        return lambda dev: synth.csr_dataset_structured_device(name, dev, **kw)
+
+    return {
+        "citation-shuffled": ds("citation", order="shuffled"), "citation-degree": ds("citation", order="degree"),
+        "ppa-shuffled": ds("ppa", order="shuffled"), "ppa-degree": ds("ppa", order="degree"),
+        "products-degree": ds("products", order="degree"),
+        "yelp-degree": ds("yelp", order="degree"), "yelp-shuffled": ds("yelp", order="shuffled"),
+        "wikikg2-shuffled": ds("wikikg2", order="shuffled"),
+        "collab-degree": ds("collab", order="degree"),
+        "reddit-shuffled": ds("reddit.dgl", order="shuffled"),
+        "protein-degree": ds("protein", order="degree"),
+        "ddi-shuffled": ds("ddi", order="shuffled"),
+        "youtube-degree": ds("youtube", order="degree"),
+        "amazon-community": ds("amazon_cogdl"),
+        "weak-sbm-1M-deg32": lambda dev: synth.csr_dcsbm_device(1 << 20, 32 << 20, 64, dev, alpha=0, mean_comm=4096, p_in=0.6, seed=77),
+        "rmat18-unpermuted": lambda dev: synth.csr_rmat_device(18, dev, seed=5),
+        "banded-wide-long-rows": lambda dev: synth.csr_banded_long_rows_device(1 << 17, dev, width=16384, seed=9),
+        "community-yelp-p05": ds("yelp", p_in=0.5),
+    }
+
+
 class Timer:
     def __init__(self):
         import torch
@@ -152,6 +179,7 @@ def main():
     ap.add_argument("--only", default=None, help="comma list of substrings")
     ap.add_argument("--lens", default="32,128,256")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--holdout", action="store_true", help="the graphs no rule was fitted on (holdout_list) instead of graph_list")
     ap.add_argument("--no-ref", action="store_true", help="skip the comparison with spmm_kernel_ref (bits are still compared with auto's)")
     ap.add_argument("--summarize", default=None)
     ap.add_argument("--before", default=None, help="with --summarize: the JSONL of the same script from before the rule fixes (adds a column)")
@@ -169,7 +197,7 @@ def main():
     tm = Timer()
     lens = [int(x) for x in args.lens.split(",")]
     only = args.only.split(",") if args.only else None
-    for gname, build in graph_list(args.quick).items():
+    for gname, build in (holdout_list() if args.holdout else graph_list(args.quick)).items():
         if only and not any(o in gname for o in only):
             continue
         t0 = time.time()
