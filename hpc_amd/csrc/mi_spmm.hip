@@ -473,6 +473,13 @@ static int plan_col_strips(mi_spmm_handle *h)
     // local columns at a narrow B: a long row's nonzeros cluster in one or two strips, the other launches find it empty -- many strips only add launches
     // (ppa-community kLen 32: 14 strips DOUBLED the step, 4 are neutral, 2 take a fifth off; reddit- / protein-community kLen 32: 2 - 4 strips 0.88 - 0.95 of the time, 6 the same as none)
     if (h->col_strips == 0 && h->local_pct >= 50 && h->feat < 128 && S > 2) S = 2;
+    // a strip is a launch: ~10 us of ramp each.  Not more strips than the step has 0.1 ms slices of work (hold-out: an R-MAT of scale 18 at kLen 32 -- 0.17 ms
+    // of bytes -- lost 30 % to six strips; every fitted case has >= 0.14 ms per strip)
+    if (h->col_strips == 0) {
+        const double step = ((double)h->nnz * (4.0 * h->feat + 8.0) + 4.0 * (double)h->num_v * h->feat) / 6e12;
+        const int64_t by_time = (int64_t)(step / 100e-6);
+        if (S > by_time) S = by_time;
+    }
     if (S > h->num_cols) S = h->num_cols;
     if (S > kMaxColStrips) S = kMaxColStrips;
     if (S < 2) return MI_SPMM_OK;
@@ -1247,8 +1254,12 @@ int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
     // (... except two tiles of 64 at N = 128 when the hubs come first in the vertex order: their B rows are the hot set, and half-width rows of it fit L2 --
     //  am-degree N = 128: 0.88 of the time with 64; the same graph at N = 256 prefers the whole wave by 0.82; arxiv-degree, whose B fits the Infinity Cache, 0.89 the other way)
     if (mean < 8) return (N <= 128 && N > 64 && hubs && h->front_pct >= 50 && 4.0 * (double)h->num_cols * (double)N > 256.0 * 1048576.0) ? 64 : 256;
-    if (N >= 256) return 64;
-    if (N >= 128 && hubs) return 64;
+    // The tiles of a wide B are swept one after the other: a sweep gathers out of K x tile x 4 bytes, and the tile is the widest whose sweep stays inside
+    // the Infinity Cache (256 MiB) -- 64 columns at K = 2^20, the whole wave once K <= 2^18 (round 5, hold-out graphs: an R-MAT of scale 18 lost 19 - 23 %
+    // to the 64-column tiles its scale-20 sibling needs).
+    const double sweep = 4.0 * (double)h->num_cols;          // bytes per column of a tile
+    if (N >= 256) return sweep * 256.0 <= 256.0 * 1048576.0 ? 256 : sweep * 128.0 <= 256.0 * 1048576.0 ? 128 : 64;
+    if (N >= 128 && hubs && sweep * (double)N > 256.0 * 1048576.0) return 64;
     return 256;
 }
 
