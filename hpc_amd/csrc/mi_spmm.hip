@@ -1254,12 +1254,11 @@ int resolve_tile_cols(const mi_spmm_handle *h, int32_t N, int64_t ldb)
     // (... except two tiles of 64 at N = 128 when the hubs come first in the vertex order: their B rows are the hot set, and half-width rows of it fit L2 --
     //  am-degree N = 128: 0.88 of the time with 64; the same graph at N = 256 prefers the whole wave by 0.82; arxiv-degree, whose B fits the Infinity Cache, 0.89 the other way)
     if (mean < 8) return (N <= 128 && N > 64 && hubs && h->front_pct >= 50 && 4.0 * (double)h->num_cols * (double)N > 256.0 * 1048576.0) ? 64 : 256;
-    // The tiles of a wide B are swept one after the other: a sweep gathers out of K x tile x 4 bytes, and the tile is the widest whose sweep stays inside
-    // the Infinity Cache (256 MiB) -- 64 columns at K = 2^20, the whole wave once K <= 2^18 (round 5, hold-out graphs: an R-MAT of scale 18 lost 19 - 23 %
-    // to the 64-column tiles its scale-20 sibling needs).
-    const double sweep = 4.0 * (double)h->num_cols;          // bytes per column of a tile
-    if (N >= 256) return sweep * 256.0 <= 256.0 * 1048576.0 ? 256 : sweep * 128.0 <= 256.0 * 1048576.0 ? 128 : 64;
-    if (N >= 128 && hubs && sweep * (double)N > 256.0 * 1048576.0) return 64;
+    // (Hold-out graphs, round 5: sizing the tile so that a sweep's K x tile x 4 bytes just fit the Infinity Cache -- the whole wave once K <= 2^18 -- gains
+    //  5 - 22 % on an R-MAT of scale 18 and LOSES 15 - 19 % on collab- / reddit- / protein-shaped graphs of the same K, whose strips or hub rows want the
+    //  narrow tile: not adopted; profiles/r05_regret_holdout.md.)
+    if (N >= 256) return 64;
+    if (N >= 128 && hubs) return 64;
     return 256;
 }
 
