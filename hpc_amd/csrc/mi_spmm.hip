@@ -67,6 +67,14 @@ struct mi_spmm_handle {
     int64_t fused_step;      // "fused_step": 2 (default) = auto, 0 = never, 1 = whenever the step is eligible: hub rows, segments and short rows as the three
                              // roles of ONE launch (spmm_kernels.hpp spmm_small_step) instead of 2-3 launches and a side-stream fork / join
     int32_t last_fused;      // 1: the last run call went through the small-step kernel
+    // "autotune" (round 5): the rules above are guesses from a 8 192-row sample and a histogram; a wrong guess is silent (same bits, slower).  With the option on,
+    // preprocess MEASURES: the step is timed on the buffers it is given (the reference's preprocess touches vout too: spmm_opt.cu:67) under the auto plan and
+    // under a handful of forced settings of the options the caller left to us -- tile width, strip count, medium threshold, one launch or several -- and the
+    // fastest is kept.  Scheduling only: whatever wins gives the same bits.
+    int64_t autotune;
+    uint32_t tuned_mask;     // options the tuner set (bit 0 tile_cols, 1 col_strips, 2 medium_thr, 3 fused_step): back to auto before the next tuning
+    int32_t tune_evals;      // candidate settings timed by the last preprocess
+    double tune_auto_ms, tune_best_ms;
     // plan
     bool prepared;
     Chunk *d_chunks;
@@ -753,7 +761,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     if (!good(h) || !key) return MI_SPMM_EINVAL;
     const std::string k(key);
     if (k == "use_graph") return MI_SPMM_EUNSUPPORTED;      // removed in round 5 (it only ever lost: profiles/r05_use_graph_experiment.md); a caller captures run() itself
-    else if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; free_plan(h); }
+    else if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; h->tuned_mask &= ~4u; free_plan(h); }
     else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
     else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
@@ -782,11 +790,12 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     }
     else if (k == "gpu_preprocess") { h->gpu_preprocess = v ? 1 : 0; free_plan(h); }
     else if (k == "split_cols") h->split_cols = v ? 1 : 0;
-    else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; }
+    else if (k == "tile_cols") { if (v != 0 && v != 32 && v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->tile_cols = v; h->tuned_mask &= ~1u; }
     else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
-    else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; free_plan(h); }
-    else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; }
+    else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; h->tuned_mask &= ~2u; free_plan(h); }
+    else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; h->tuned_mask &= ~8u; }
     else if (k == "segment_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->seg_order = v; free_plan(h); }
+    else if (k == "autotune") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->autotune = v; free_plan(h); }
     else if (k == "col_strips_builder") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->strips_builder = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -837,6 +846,11 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "col_strips_builder") *value = h->strips_builder;
     else if (k == "fused_step") *value = h->fused_step;
     else if (k == "segment_order") *value = h->seg_order;
+    else if (k == "autotune") *value = h->autotune;
+    else if (k == "autotune_evals") *value = h->tune_evals;
+    else if (k == "autotune_auto_us") *value = (int64_t)(h->tune_auto_ms * 1e3);
+    else if (k == "autotune_best_us") *value = (int64_t)(h->tune_best_ms * 1e3);
+    else if (k == "autotune_mask") *value = h->tuned_mask;
     else if (k == "fused_step_in_force") *value = h->last_fused;
     else if (k == "segment_nnz") *value = h->seg_nnz;
     else if (k == "col_strips_table_hash") {           // FNV-1a over the strip tables (copied back: a test's question, not a step's)
@@ -1634,11 +1648,93 @@ static int launch_set(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float 
 }
 
 
+// "autotune": time the step under the plan in force (nothing else: no allocation beyond two events).  One warm-up, then enough runs for ~1 ms.
+static int time_step(mi_spmm_handle *h, const float *d_vin, float *d_vout, hipEvent_t e0, hipEvent_t e1, double *ms_out)
+{
+    PeerOut po;
+    std::memset(&po, 0, sizeof(po));
+    const double est_ms = ((double)h->nnz * (4.0 * h->feat + 8.0) + 4.0 * (double)h->num_v * h->feat) / 8e9;
+    int reps = (int)(1.0 / (est_ms > 0.01 ? est_ms : 0.01)) + 1;
+    reps = reps < 3 ? 3 : (reps > 20 ? 20 : reps);
+    double best = 1e30;
+    for (int batch = 0; batch < 2; ++batch) {                  // (min of two batches; the first also warms the plan's tables up)
+        int rc = launch_set(h, d_vin, h->feat, d_vout, h->feat, 0, h->num_v, po, nullptr);
+        if (rc != MI_SPMM_OK) return rc;
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps && rc == MI_SPMM_OK; ++i) rc = launch_set(h, d_vin, h->feat, d_vout, h->feat, 0, h->num_v, po, nullptr);
+        if (rc != MI_SPMM_OK) return rc;
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if ((double)ms / reps < best) best = (double)ms / reps;
+    }
+    *ms_out = best;
+    return MI_SPMM_OK;
+}
+
+static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MI_SPMM_ENOMEM; }
+    struct Cfg { int64_t tile, strips, mthr, fused; };
+    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; };
+    // what the caller left to us (an explicit value of the caller's is never touched); the plan of these settings is the one in force
+    const bool own_tile = h->tile_cols == 0, own_strips = h->col_strips == 0, own_mthr = h->medium_thr == 0, own_fused = h->fused_step == 2;
+    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step};
+    double best_ms = 0.0;
+    int rc = time_step(h, d_vin, d_vout, e0, e1, &best_ms);
+    h->tune_auto_ms = best_ms;
+    h->tune_evals = 0;
+    const int32_t N = h->feat, S_auto = h->n_strips, tile_auto = h->last_lpr * 4, mthr_auto = (int32_t)h->medium_res;
+    const bool fused_auto = h->last_fused != 0;
+    auto consider = [&](Cfg c) {
+        if (rc != MI_SPMM_OK) return;
+        apply(c);
+        rc = preprocess_plan(h);
+        double ms = 0.0;
+        if (rc == MI_SPMM_OK) rc = time_step(h, d_vin, d_vout, e0, e1, &ms);
+        if (rc != MI_SPMM_OK) return;
+        ++h->tune_evals;
+        if (ms < 0.97 * best_ms) { best = c; best_ms = ms; }    // 3 %: a candidate has to beat the noise of a 1 ms measurement
+    };
+    // one option at a time, each sweep starting from the best so far (the options interact little once the plan class is fixed: scripts/regret.py)
+    if (own_mthr) for (int64_t m : {32, 64, 256, 1024}) if (m != mthr_auto) { Cfg c = best; c.mthr = m; consider(c); }
+    if (own_strips) {
+        const int64_t cand[3] = {1, S_auto > 1 ? (S_auto / 2 > 1 ? S_auto / 2 : 2) : 4, S_auto > 1 ? (2 * S_auto < kMaxColStrips ? 2 * S_auto : kMaxColStrips) : 12};
+        for (int64_t sc : cand) if (sc != S_auto) { Cfg c = best; c.strips = sc; consider(c); }
+    }
+    if (own_tile && N > 64) for (int64_t t : {64, 128, 256}) if (t != tile_auto && (t < N || t == 256) && !(t == 256 && tile_auto >= N)) { Cfg c = best; c.tile = t; consider(c); }
+    if (own_fused) { Cfg c = best; c.fused = fused_auto ? 0 : 1; consider(c); }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step}); return rc; }
+    apply(best);
+    h->tuned_mask = (own_tile && best.tile != 0 ? 1u : 0u) | (own_strips && best.strips != 0 ? 2u : 0u) | (own_mthr && best.mthr != 0 ? 4u : 0u) |
+                    (own_fused && best.fused != 2 ? 8u : 0u);
+    h->tune_best_ms = best_ms;
+    return preprocess_plan(h);              // the winner's plan (also when the winner is the auto plan: the last candidate's tables are in place otherwise)
+}
+
 int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
 {
-    // the reference zeroes vout here (spmm_opt.cu:67-68) because its kernel accumulates; ours overwrites, so vout is left alone
+    // the reference zeroes vout here (spmm_opt.cu:67-68) because its kernel accumulates; ours overwrites, so vout is left alone -- unless "autotune" is on
+    if (good(h) && h->tuned_mask) {         // what an earlier tuning set goes back to auto: tuned again below, or simply auto when the option is off now
+        if (h->tuned_mask & 1u) h->tile_cols = 0;
+        if (h->tuned_mask & 2u) h->col_strips = 0;
+        if (h->tuned_mask & 4u) h->medium_thr = 0;
+        if (h->tuned_mask & 8u) h->fused_step = 2;
+        h->tuned_mask = 0;
+    }
     const int rc = preprocess_plan(h);
     if (rc != MI_SPMM_OK) return rc;
+    if (h->autotune && d_vin && d_vout && h->num_v > 0 && h->feat >= 4 && h->nnz > 0 && !h->split_long) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int trc = autotune_plan(h, d_vin, d_vout);
+        if (trc != MI_SPMM_OK) return trc;
+        h->preprocess_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
     return MI_SPMM_OK;
 }
 

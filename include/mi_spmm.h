@@ -159,6 +159,13 @@ const char *mi_spmm_strerror(int code);
  *                         block groups, default cache policy.  auto: only steps whose bytes take under 0.2 ms at 6 TB/s (there the launch
  *                         boundaries are a third of the step; the rows role runs at the hub role's footprint, 3 waves per SIMD).  1: whenever
  *                         eligible.  Same device functions, same arithmetic: same bits.  Read-only "fused_step_in_force": the last run used it
+ *   "autotune"            0 (default) / 1: the rules behind the options above are guesses from a row sample and a histogram, and a wrong guess is silent
+ *                         (same bits, slower).  With 1, preprocess MEASURES instead: the step is timed on the vin / vout it is given -- vout is written,
+ *                         as the reference's preprocess does (spmm_opt.cu:67) -- under the auto plan and under a dozen forced settings of the options the
+ *                         caller left at auto ("medium_row_threshold", "col_strips", "tile_cols", "fused_step"; an explicit value of the caller's is
+ *                         never touched), one option at a time, and the fastest is kept (it has to win by 3 %).  Costs a dozen plans and ~50 steps of
+ *                         preprocess time; scheduling only: same bits.  Afterwards the tuned options read back their chosen values; read-only
+ *                         "autotune_evals", "autotune_auto_us", "autotune_best_us", "autotune_mask" (bit 0 tile, 1 strips, 2 medium, 3 fused: what it changed)
  *   ("use_graph", round 4 -- the handle capturing its own launch set into a HIP graph and replaying it -- was removed in round 5: it lost on every graph,
  *    launched on the caller's stream or on a tested stream of its own, profiles/r05_use_graph_experiment.md; the key answers MI_SPMM_EUNSUPPORTED.  run()
  *    allocates nothing and synchronises nothing, so a caller can still capture it into a graph of its own: test_run_is_graph_capturable_and_stream_ordered.)

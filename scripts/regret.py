@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--only", default=None, help="comma list of substrings")
     ap.add_argument("--lens", default="32,128,256")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="the handle under test has \"autotune\" = 1 (preprocess measures instead of guessing): its regret against the same forced grid")
     ap.add_argument("--holdout", action="store_true", help="the graphs no rule was fitted on (holdout_list) instead of graph_list")
     ap.add_argument("--no-ref", action="store_true", help="skip the comparison with spmm_kernel_ref (bits are still compared with auto's)")
     ap.add_argument("--summarize", default=None)
@@ -228,13 +229,17 @@ def main():
                     op.run(d_B, out)
                 return min(tm.batch(lambda: op.run(d_B, out), reps) for _ in range(3))
 
-            auto = make({})
+            auto = make({"autotune": 1} if args.autotune else {})
             auto_ms = measure(auto, d_auto)
             acfg = {"thr": auto.get_option("long_row_threshold"), "S": auto.get_option("n_col_strips"), "tile": auto.get_option("lanes_per_row") * 4,
                     "mthr": auto.get_option("medium_row_threshold"), "hubs": auto.get_option("n_hub_rows"), "segments": auto.get_option("n_chunks"),
                     "seg_nnz_pct": round(100.0 * auto.get_option("segment_nnz") / max(1, nnz), 1), "locality_pct": auto.get_option("column_locality_pct"),
                     "unsorted": auto.get_option("segments_unsorted"), "launches": auto.get_option("n_launches"), "preprocess_us": auto.get_option("preprocess_us"),
                     "fused": auto.get_option("fused_step_in_force"), "front_pct": auto.get_option("column_front_pct")}
+            if args.autotune:
+                acfg.update({"autotune_evals": auto.get_option("autotune_evals"), "autotune_mask": auto.get_option("autotune_mask"),
+                             "autotune_auto_us": auto.get_option("autotune_auto_us"), "autotune_best_us": auto.get_option("autotune_best_us"),
+                             "tuned": {k: auto.get_option(k) for k in ("tile_cols", "col_strips", "medium_row_threshold", "fused_step")}})
             ref_diff = None
             if not args.no_ref and oracle.ref_available():
                 d_R = torch.zeros((M, N), device=dev)

@@ -1705,3 +1705,45 @@ def test_fold_falls_back_to_the_hub_plan_when_a_former_hub_is_unsorted(device, o
     assert op.get_option("n_hub_rows") >= 1 and op.get_option("long_row_threshold") < 1 << 30
     assert op.get_option("n_col_strips") >= 2 and op.get_option("segments_unsorted") == 0
     assert np.array_equal(bits(C), bits(oracle.spmm_omp(ptr, idx, vals, B)))
+
+
+def test_autotune_measures_keeps_the_callers_values_and_every_bit(device, oracle):
+    """ "autotune" = 1: preprocess times the step under the auto plan and under forced settings of the options the caller left at auto, and keeps the fastest.
+    Scheduling only: the bits are the oracle's whatever it picks; an explicit value of the caller's is never changed; a second preprocess starts from auto
+    again; switching the option off restores the rules."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+
+    M = K = 40000
+    N = 128
+    ptr, idx = _strip_case(M, K, 20, 200, seed=71, hubs=(3000, 9000))
+    vals = synth.normal_f32(idx.size, 72)
+    B = synth.normal_f32(K * N, 73).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    d_ptr, d_idx, d_val, d_B = to_dev(device, ptr, idx, vals, B)
+    d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    op = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N)
+    op.set_option("fused_step", 2)
+    op.set_option("autotune", 1)
+    op.set_option("tile_cols", 128)                  # the caller's: not the tuner's to change
+    op.preprocess(d_B, d_C)
+    assert op.get_option("autotune_evals") >= 5 and op.get_option("tile_cols") == 128 and not (op.get_option("autotune_mask") & 1)
+    assert 0 < op.get_option("autotune_best_us") <= op.get_option("autotune_auto_us")
+    chosen = {k: op.get_option(k) for k in ("col_strips", "medium_row_threshold", "fused_step")}
+    mask = op.get_option("autotune_mask")
+    assert (chosen["col_strips"] != 0) == bool(mask & 2) and (chosen["fused_step"] != 2) == bool(mask & 8)
+    d_C.fill_(float("nan"))
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    op.preprocess(d_B, d_C)                          # again: from auto, not from the last winner
+    assert op.get_option("autotune_evals") >= 5
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    op.set_option("autotune", 0)
+    op.preprocess(d_B, d_C)
+    assert op.get_option("autotune_mask") == 0 and op.get_option("col_strips") == 0 and op.get_option("fused_step") == 2 and op.get_option("tile_cols") == 128
+    op.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
