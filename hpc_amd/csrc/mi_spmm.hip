@@ -72,7 +72,7 @@ struct mi_spmm_handle {
     // under a handful of forced settings of the options the caller left to us -- tile width, strip count, medium threshold, one launch or several -- and the
     // fastest is kept.  Scheduling only: whatever wins gives the same bits.
     int64_t autotune;
-    uint32_t tuned_mask;     // options the tuner set (bit 0 tile_cols, 1 col_strips, 2 medium_thr, 3 fused_step): back to auto before the next tuning
+    uint32_t tuned_mask;     // options the tuner set (bit 0 tile_cols, 1 col_strips, 2 medium_thr, 3 fused_step, 4 segment_order): back to auto before the next tuning
     int32_t tune_evals;      // candidate settings timed by the last preprocess
     double tune_auto_ms, tune_best_ms;
     // plan
@@ -794,7 +794,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; h->tuned_mask &= ~2u; free_plan(h); }
     else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; h->tuned_mask &= ~8u; }
-    else if (k == "segment_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->seg_order = v; free_plan(h); }
+    else if (k == "segment_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->seg_order = v; h->tuned_mask &= ~16u; free_plan(h); }
     else if (k == "autotune") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->autotune = v; free_plan(h); }
     else if (k == "col_strips_builder") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->strips_builder = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
@@ -1678,11 +1678,11 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MI_SPMM_ENOMEM; }
-    struct Cfg { int64_t tile, strips, mthr, fused; };
-    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; };
+    struct Cfg { int64_t tile, strips, mthr, fused, order; };
+    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; h->seg_order = c.order; };
     // what the caller left to us (an explicit value of the caller's is never touched); the plan of these settings is the one in force
-    const bool own_tile = h->tile_cols == 0, own_strips = h->col_strips == 0, own_mthr = h->medium_thr == 0, own_fused = h->fused_step == 2;
-    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step};
+    const bool own_tile = h->tile_cols == 0, own_strips = h->col_strips == 0, own_mthr = h->medium_thr == 0, own_fused = h->fused_step == 2, own_order = h->seg_order == 0;
+    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step, h->seg_order};
     double best_ms = 0.0;
     int rc = time_step(h, d_vin, d_vout, e0, e1, &best_ms);
     h->tune_auto_ms = best_ms;
@@ -1707,12 +1707,13 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     }
     if (own_tile && N > 64) for (int64_t t : {64, 128, 256}) if (t != tile_auto && (t < N || t == 256) && !(t == 256 && tile_auto >= N)) { Cfg c = best; c.tile = t; consider(c); }
     if (own_fused) { Cfg c = best; c.fused = fused_auto ? 0 : 1; consider(c); }
+    if (own_order && h->n_chunks > 0) { Cfg c = best; c.order = 2; consider(c); }        // segments as the rows come (auto: by length)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step}); return rc; }
+    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step, own_order ? 0 : h->seg_order}); return rc; }
     apply(best);
     h->tuned_mask = (own_tile && best.tile != 0 ? 1u : 0u) | (own_strips && best.strips != 0 ? 2u : 0u) | (own_mthr && best.mthr != 0 ? 4u : 0u) |
-                    (own_fused && best.fused != 2 ? 8u : 0u);
+                    (own_fused && best.fused != 2 ? 8u : 0u) | (own_order && best.order != 0 ? 16u : 0u);
     h->tune_best_ms = best_ms;
     return preprocess_plan(h);              // the winner's plan (also when the winner is the auto plan: the last candidate's tables are in place otherwise)
 }
@@ -1725,6 +1726,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         if (h->tuned_mask & 2u) h->col_strips = 0;
         if (h->tuned_mask & 4u) h->medium_thr = 0;
         if (h->tuned_mask & 8u) h->fused_step = 2;
+        if (h->tuned_mask & 16u) h->seg_order = 0;
         h->tuned_mask = 0;
     }
     const int rc = preprocess_plan(h);
