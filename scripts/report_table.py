@@ -45,15 +45,11 @@ def timed(f, warm, reps):
 
 
 def gather_rate(b_bytes):
-    """The gather rate a B of that size allows (MI355X_MICROARCH.md "Indexed rows": rows shared through an XCD's 4 MiB L2 18 TB/s; a table in the Infinity
-    Cache 8.6 TB/s, its L2 share (4 MiB / T) at the L2 rate; beyond 256 MiB the HBM peak, 8 TB/s)."""
-    mib = 1048576.0
-    if b_bytes <= 4 * mib:
-        return 18e12
-    if b_bytes <= 256 * mib:
-        share = 4 * mib / b_bytes
-        return 1.0 / (share / 18e12 + (1.0 - share) / 8.6e12)
-    return 8e12
+    """The gather rate a B of that size ALLOWS -- a floor, so the best case: a B the Infinity Cache holds (<= 256 MiB) can be gathered strip by strip out
+    of an XCD's L2 at the L2's rate, 18 TB/s chip-wide (MI355X_MICROARCH.md "Indexed rows": 16.8 - 18.8 for rows shared through L2); beyond
+    that the HBM peak, 8 TB/s.  (A first form interpolated the Infinity Cache's 8.6 TB/s for 4 - 256 MiB: protein- / reddit-shaped graphs in strips ran
+    at 0.5 - 0.7 of that "floor".)"""
+    return 18e12 if b_bytes <= 256 * 1048576.0 else 8e12
 
 
 def floor_seconds(M, N, nnz, longest):
