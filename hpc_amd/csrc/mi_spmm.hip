@@ -64,6 +64,7 @@ struct mi_spmm_handle {
     int64_t seg_nnz;         // nonzeros in the whole segments (either plan builder): the strip rule's input, known before any column is read
     int64_t strips_builder;  // 0 (default): strip_segments, one pass; 1: the round-4 pair survey_segments + build_col_strips (cross-check)
     int64_t seg_order;       // "segment_order": 0 = auto, 1 = segments longest first, 2 = in row order
+    int64_t rows_unroll;     // "rows_unroll": B-row gathers in flight per lane group in the rows kernel: 0 = auto, 8, 16
     int64_t fused_step;      // "fused_step": 2 (default) = auto, 0 = never, 1 = whenever the step is eligible: hub rows, segments and short rows as the three
                              // roles of ONE launch (spmm_kernels.hpp spmm_small_step) instead of 2-3 launches and a side-stream fork / join
     int32_t last_fused;      // 1: the last run call went through the small-step kernel
@@ -796,6 +797,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; h->tuned_mask &= ~8u; }
     else if (k == "segment_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->seg_order = v; h->tuned_mask &= ~16u; free_plan(h); }
     else if (k == "autotune") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->autotune = v; free_plan(h); }
+    else if (k == "rows_unroll") { if (v != 0 && v != 8 && v != 16) return MI_SPMM_EINVAL; h->rows_unroll = v; }
     else if (k == "col_strips_builder") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->strips_builder = v; free_plan(h); }
     else if (k == "block_threads") { if (v != 64 && v != 128 && v != 256) return MI_SPMM_EINVAL; h->block_threads = v; }
     else if (k == "nt_store") h->nt_store = v ? 1 : 0;
@@ -847,6 +849,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "fused_step") *value = h->fused_step;
     else if (k == "segment_order") *value = h->seg_order;
     else if (k == "autotune") *value = h->autotune;
+    else if (k == "rows_unroll") *value = h->rows_unroll;
     else if (k == "autotune_evals") *value = h->tune_evals;
     else if (k == "autotune_auto_us") *value = (int64_t)(h->tune_auto_ms * 1e3);
     else if (k == "autotune_best_us") *value = (int64_t)(h->tune_best_ms * 1e3);
@@ -1159,6 +1162,17 @@ void launch_rows_v2_fixed(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
     case 16: hipLaunchKernelGGL((spmm_rows_v2<V, 16, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
     case 32: hipLaunchKernelGGL((spmm_rows_v2<V, 32, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((spmm_rows_v2<V, 64, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
+    }
+}
+// 16 gathers in flight per lane group (default cache policy, 256-thread workgroups): rows of hundreds of nonzeros, which the medium rule now leaves in this
+// kernel where the columns are local, are one dependent chain per lane group each
+void launch_rows_v2_deep(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
+{
+    switch (lpr) {
+    case 8: hipLaunchKernelGGL((spmm_rows_v2<4, 8, 16, false, 1, 256>), grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((spmm_rows_v2<4, 16, 16, false, 1, 256>), grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((spmm_rows_v2<4, 32, 16, false, 1, 256>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((spmm_rows_v2<4, 64, 16, false, 1, 256>), grid, dim3(256), 0, s, a); break;
     }
 }
 void launch_rows_v2_any(bool vec4, bool wide, int lpr, int bt, int pol, const RowsArgs &a, dim3 grid, hipStream_t s)
@@ -1542,6 +1556,7 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     // every row may already be owned by the segment, split and block paths: nothing left to launch
     const bool rows_needed = !((blocks_on || h->n_blk_groups == 0) && h->n_rows_for_rows_kernel == 0);
     if (!rows_needed) { /* skip */ }
+    else if (h->rows_unroll == 16 && vec4 && !wide && bt == kBlockThreads && pol == kPolNtStore) launch_rows_v2_deep(lpr, a, grid, s);
     else launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
     if (rows_needed) ++launches;
 
