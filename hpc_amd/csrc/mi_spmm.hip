@@ -1164,8 +1164,8 @@ void launch_rows_v2_fixed(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
     default: hipLaunchKernelGGL((spmm_rows_v2<V, 64, 8, WIDE, 1, 256>), grid, dim3(256), 0, s, a); break;
     }
 }
-// 16 gathers in flight per lane group (default cache policy, 256-thread workgroups): rows of hundreds of nonzeros, which the medium rule now leaves in this
-// kernel where the columns are local, are one dependent chain per lane group each
+// "rows_unroll" = 16: sixteen gathers in flight per lane group (default cache policy, 256-thread workgroups only).  Half the round trips per row at two
+// thirds of the occupancy: -13 % ... +23 % by graph (profiles/r05_rows_unroll_ab.txt), so never the rule's choice; "autotune" tries it
 void launch_rows_v2_deep(int lpr, const RowsArgs &a, dim3 grid, hipStream_t s)
 {
     switch (lpr) {
@@ -1693,11 +1693,12 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MI_SPMM_ENOMEM; }
-    struct Cfg { int64_t tile, strips, mthr, fused, order; };
-    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; h->seg_order = c.order; };
+    struct Cfg { int64_t tile, strips, mthr, fused, order, unroll; };
+    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; h->seg_order = c.order; h->rows_unroll = c.unroll; };
     // what the caller left to us (an explicit value of the caller's is never touched); the plan of these settings is the one in force
     const bool own_tile = h->tile_cols == 0, own_strips = h->col_strips == 0, own_mthr = h->medium_thr == 0, own_fused = h->fused_step == 2, own_order = h->seg_order == 0;
-    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step, h->seg_order};
+    const bool own_unroll = h->rows_unroll == 0;
+    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step, h->seg_order, h->rows_unroll};
     double best_ms = 0.0;
     int rc = time_step(h, d_vin, d_vout, e0, e1, &best_ms);
     h->tune_auto_ms = best_ms;
@@ -1723,12 +1724,15 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     if (own_tile && N > 64) for (int64_t t : {64, 128, 256}) if (t != tile_auto && (t < N || t == 256) && !(t == 256 && tile_auto >= N)) { Cfg c = best; c.tile = t; consider(c); }
     if (own_fused) { Cfg c = best; c.fused = fused_auto ? 0 : 1; consider(c); }
     if (own_order && h->n_chunks > 0) { Cfg c = best; c.order = 2; consider(c); }        // segments as the rows come (auto: by length)
+    // 16 gathers in flight per lane group of the rows kernel (auto: 8): -13 % on banded 300-700 rows at N = 256, -8 % on rows of 4 - 12 at N = 128 / 256,
+    // -1 % on C1 / C2, +4 ... +23 % on community-ordered graphs (occupancy): no rule of the plan's statistics separates them (profiles/r05_rows_unroll_ab.txt)
+    if (own_unroll && h->last_fused == 0) { Cfg c = best; c.unroll = 16; consider(c); }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step, own_order ? 0 : h->seg_order}); return rc; }
+    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step, own_order ? 0 : h->seg_order, own_unroll ? 0 : h->rows_unroll}); return rc; }
     apply(best);
     h->tuned_mask = (own_tile && best.tile != 0 ? 1u : 0u) | (own_strips && best.strips != 0 ? 2u : 0u) | (own_mthr && best.mthr != 0 ? 4u : 0u) |
-                    (own_fused && best.fused != 2 ? 8u : 0u) | (own_order && best.order != 0 ? 16u : 0u);
+                    (own_fused && best.fused != 2 ? 8u : 0u) | (own_order && best.order != 0 ? 16u : 0u) | (own_unroll && best.unroll != 0 ? 32u : 0u);
     h->tune_best_ms = best_ms;
     return preprocess_plan(h);              // the winner's plan (also when the winner is the auto plan: the last candidate's tables are in place otherwise)
 }
@@ -1742,6 +1746,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         if (h->tuned_mask & 4u) h->medium_thr = 0;
         if (h->tuned_mask & 8u) h->fused_step = 2;
         if (h->tuned_mask & 16u) h->seg_order = 0;
+        if (h->tuned_mask & 32u) h->rows_unroll = 0;
         h->tuned_mask = 0;
     }
     const int rc = preprocess_plan(h);

@@ -162,13 +162,17 @@ const char *mi_spmm_strerror(int code);
  *   "segment_order"       0 (default, auto) / 1: the segment table is sorted longest first (the lane groups of a wave carry similar lengths) / 2: it stays
  *                         in row order (neighbouring rows -- which gather the same B rows where the columns are local -- stay together).  auto = 1: row
  *                         order measured mixed on structured graphs (profiles/r05_regret.md); "autotune" tries it.  Scheduling only
+ *   "rows_unroll"         0 (default, auto = 8) / 8 / 16: B-row gathers a lane group of the rows kernel keeps in flight per batch of its row's chain (16 only
+ *                         on the plain path: 4-float lanes, 32-bit offsets, 256-thread workgroups, default cache policy; elsewhere 8 stays in force).  16 halves
+ *                         the round trips of a row and costs occupancy: -13 % ... +23 % by graph, no rule separates them (profiles/r05_rows_unroll_ab.txt), so
+ *                         auto stays 8 and "autotune" tries 16.  Same chain per row: same bits
  *   "autotune"            0 (default) / 1: the rules behind the options above are guesses from a row sample and a histogram, and a wrong guess is silent
  *                         (same bits, slower).  With 1, preprocess MEASURES instead: the step is timed on the vin / vout it is given -- vout is written,
  *                         as the reference's preprocess does (spmm_opt.cu:67) -- under the auto plan and under a dozen forced settings of the options the
- *                         caller left at auto ("medium_row_threshold", "col_strips", "tile_cols", "fused_step", "segment_order"; an explicit value of the caller's is
+ *                         caller left at auto ("medium_row_threshold", "col_strips", "tile_cols", "fused_step", "segment_order", "rows_unroll"; an explicit value of the caller's is
  *                         never touched), one option at a time, and the fastest is kept (it has to win by 3 %).  Costs a dozen plans and ~50 steps of
  *                         preprocess time; scheduling only: same bits.  Afterwards the tuned options read back their chosen values; read-only
- *                         "autotune_evals", "autotune_auto_us", "autotune_best_us", "autotune_mask" (bit 0 tile, 1 strips, 2 medium, 3 fused, 4 segment order: what it changed)
+ *                         "autotune_evals", "autotune_auto_us", "autotune_best_us", "autotune_mask" (bit 0 tile, 1 strips, 2 medium, 3 fused, 4 segment order, 5 rows unroll: what it changed)
  *   ("use_graph", round 4 -- the handle capturing its own launch set into a HIP graph and replaying it -- was removed in round 5: it lost on every graph,
  *    launched on the caller's stream or on a tested stream of its own, profiles/r05_use_graph_experiment.md; the key answers MI_SPMM_EUNSUPPORTED.  run()
  *    allocates nothing and synchronises nothing, so a caller can still capture it into a graph of its own: test_run_is_graph_capturable_and_stream_ordered.)

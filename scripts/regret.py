@@ -142,7 +142,7 @@ def summarize(path, before=None):
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     worst = []
     short = {"long_row_threshold": "thr", "col_strips": "strips", "tile_cols": "tile", "medium_row_threshold": "mthr", "segment_overlap": "seg_ov", "hub_overlap": "hub_ov",
-             "hub_slice": "slice", "fused_step": "fused", "segment_order": "seg_order"}
+             "hub_slice": "slice", "fused_step": "fused", "segment_order": "seg_order", "rows_unroll": "unroll"}
 
     def fmt(cfg):
         return ", ".join(f"{short.get(k, k)}={'none' if v == NONE_THR else v}" for k, v in cfg.items()) or "(auto)"
@@ -297,7 +297,7 @@ def main():
             # one option at a time from auto: which RULE is at fault when the best forced setting changes several at once
             marg = {}
             for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128, 256, 512, 1024]), ("segment_order", [1, 2]),
-                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else []), ("fused_step", [0, 1])):
+                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else []), ("fused_step", [0, 1]), ("rows_unroll", [16])):
                 for v_ in vals_:
                     consider({key_: v_})
                     ms_, _ = evaluate({key_: v_})
@@ -345,6 +345,7 @@ def main():
                     cur = dict(best[0])
                     for S in strips:
                         consider(dict(cur, col_strips=S))
+                    consider(dict(best[0], rows_unroll=16))
             # the medium threshold and hub_overlap for the small graphs too (coordinate sweeps at the best point)
             if nnz < args.full_grid_below:
                 cur = dict(best[0])
@@ -356,6 +357,7 @@ def main():
                 cur = dict(best[0])
                 for ho in (0, 2):
                     consider(dict(cur, hub_overlap=ho))
+                consider(dict(best[0], rows_unroll=16))
             # auto against the best forced setting, interleaved
             best_cfg, best_ms = best
             a_ms, b_ms = auto_ms, best_ms

@@ -1744,6 +1744,29 @@ def test_autotune_measures_keeps_the_callers_values_and_every_bit(device, oracle
     op.set_option("autotune", 0)
     op.preprocess(d_B, d_C)
     assert op.get_option("autotune_mask") == 0 and op.get_option("col_strips") == 0 and op.get_option("fused_step") == 2 and op.get_option("tile_cols") == 128
+    assert op.get_option("rows_unroll") == 0
     op.run(d_B, d_C)
     torch.cuda.synchronize()
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [4, 32, 64, 100, 128, 256, 384])
+def test_rows_unroll_16_same_bits(device, oracle, N):
+    """ "rows_unroll" = 16: the rows kernel keeps sixteen B-row gathers in flight per lane group instead of eight -- the same fma chain per row in stored
+    order (spmm_ref.cu:10-14), so the same bits: rows of 0 .. 70 nonzeros (empty rows, rows shorter than one batch, rows of several batches plus a tail),
+    every lane-group width, two column tiles (384), a width with a partial tile (100).  Values other than 0 / 8 / 16 are refused."""
+    M = K = 6000
+    rng = np.random.default_rng(5)
+    deg = rng.integers(0, 71, M).astype(np.int64)
+    deg[:64] = np.arange(64) % 35
+    ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    idx = rng.integers(0, K, int(ptr[-1])).astype(np.int32)
+    vals = synth.normal_f32(idx.size, 81)
+    B = synth.normal_f32(K * N, 82).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, B)
+    C, op = run_spmm(device, ptr, idx, vals, B, options={"rows_unroll": 16, "medium_row_threshold": 1024})
+    assert op.get_option("rows_unroll") == 16 and op.get_option("n_chunks") == 0
+    assert np.array_equal(bits(C), bits(exp))
+    with pytest.raises(MiSpmmError):
+        op.set_option("rows_unroll", 12)
