@@ -1756,6 +1756,8 @@ def test_rows_unroll_16_same_bits(device, oracle, N):
     """ "rows_unroll" = 16: the rows kernel keeps sixteen B-row gathers in flight per lane group instead of eight -- the same fma chain per row in stored
     order (spmm_ref.cu:10-14), so the same bits: rows of 0 .. 70 nonzeros (empty rows, rows shorter than one batch, rows of several batches plus a tail),
     every lane-group width, two column tiles (384), a width with a partial tile (100).  Values other than 0 / 8 / 16 are refused."""
+    from hpc_amd.spmm import MiSpmmError
+
     M = K = 6000
     rng = np.random.default_rng(5)
     deg = rng.integers(0, 71, M).astype(np.int64)
