@@ -68,6 +68,8 @@ struct mi_spmm_handle {
     int64_t fused_step;      // "fused_step": 2 (default) = auto, 0 = never, 1 = whenever the step is eligible: hub rows, segments and short rows as the three
                              // roles of ONE launch (spmm_kernels.hpp spmm_small_step) instead of 2-3 launches and a side-stream fork / join
     int32_t last_fused;      // 1: the last run call went through the small-step kernel
+    int64_t fused_order;     // "fused_order": 0 (default) = auto, 1 = hub workgroups first in the small-step grid, 2 = segment workgroups first
+    int32_t last_seg_first;  // 1: the last small-step launch put its segment workgroups first
     // "autotune" (round 5): the rules above are guesses from a 8 192-row sample and a histogram; a wrong guess is silent (same bits, slower).  With the option on,
     // preprocess MEASURES: the step is timed on the buffers it is given (the reference's preprocess touches vout too: spmm_opt.cu:67) under the auto plan and
     // under a handful of forced settings of the options the caller left to us -- tile width, strip count, medium threshold, one launch or several -- and the
@@ -718,6 +720,7 @@ int mi_spmm_create(mi_spmm_handle **out, const int32_t *d_row_ptr, const int32_t
     h->block_threads = 256;
     h->split_cols = 1;
     h->fused_step = 2;      // auto (run_part: short steps only)
+    h->fused_order = 0;     // auto (run_part: the role whose longest chain lasts longest goes first)
     h->col_strips = 0;      // auto (plan.hpp resolve_col_strips)
     h->n_strips = 1;
     h->seg_unsorted = -1;
@@ -795,6 +798,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     else if (k == "segment_unroll") { if (v != 0 && v != 8 && v != 16 && v != 32) return MI_SPMM_EINVAL; h->segment_unroll = v; }
     else if (k == "col_strips") { if (v < 0 || v > kMaxColStrips) return MI_SPMM_EINVAL; h->col_strips = v; h->tuned_mask &= ~2u; free_plan(h); }
     else if (k == "fused_step") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_step = v; h->tuned_mask &= ~8u; }
+    else if (k == "fused_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->fused_order = v; }
     else if (k == "segment_order") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->seg_order = v; h->tuned_mask &= ~16u; free_plan(h); }
     else if (k == "autotune") { if (v != 0 && v != 1) return MI_SPMM_EINVAL; h->autotune = v; free_plan(h); }
     else if (k == "rows_unroll") { if (v != 0 && v != 8 && v != 16) return MI_SPMM_EINVAL; h->rows_unroll = v; }
@@ -855,6 +859,8 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "autotune_best_us") *value = (int64_t)(h->tune_best_ms * 1e3);
     else if (k == "autotune_mask") *value = h->tuned_mask;
     else if (k == "fused_step_in_force") *value = h->last_fused;
+    else if (k == "fused_order") *value = h->fused_order;
+    else if (k == "fused_order_in_force") *value = h->last_fused ? (h->last_seg_first ? 2 : 1) : 0;
     else if (k == "segment_nnz") *value = h->seg_nnz;
     else if (k == "col_strips_table_hash") {           // FNV-1a over the strip tables (copied back: a test's question, not a step's)
         *value = 0;
@@ -1391,6 +1397,19 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
             fa.r.long_thr = (int32_t)h->medium_res; fa.r.nblk = (int)nblk64; fa.r.flags = flags; fa.r.po = po;
             const int rows_wgs = h->n_rows_for_rows_kernel > 0 ? (int)nblk64 : 0;       // every row may belong to the first two roles (ddi-shaped graphs)
             if (fa.hub_wgs + fa.seg_wgs + rows_wgs == 0) { *launches_out += 0; return MI_SPMM_OK; }
+            // Which of the first two roles leads the grid (workgroups start in blockIdx order): the one whose longest chain LASTS longest.  A hub row costs
+            // 3.2 ns per nonzero plus ~2 us of pipeline fill; a segment is one lane group's dependent gather chain, 47 ns per nonzero (30 out of an
+            // L2-resident B), and the longest segment is as long as the hub threshold allows.  arxiv- / youtube- / am-shaped: one hub row of 10^4 - 10^5
+            // nonzeros is the step -> hubs first; ddi- / collab-shaped: hub rows of 700 - 1 800 nonzeros (2 - 6 us) over 256 - 512-nonzero segments
+            // (12 - 24 us) that used to START behind two rounds of hub workgroups -> segments first.
+            {
+                const bool l2_b = 4.0 * (double)h->num_cols * (double)full.N <= 6.0 * 1048576.0;
+                const int64_t seg_max = h->long_thr > 0 && h->long_thr < (int64_t)h->max_row_nnz ? h->long_thr : (int64_t)h->max_row_nnz;
+                const double t_seg = (double)seg_max * (l2_b ? 30e-9 : 47e-9), t_hub = 2e-6 + (double)h->max_row_nnz * 3.2e-9;
+                const bool both = fa.hub_wgs > 0 && fa.seg_wgs > 0;
+                fa.seg_first = both && (h->fused_order == 2 || (h->fused_order == 0 && t_seg > t_hub)) ? 1 : 0;
+                h->last_seg_first = fa.seg_first;
+            }
             dim3 fgrid((unsigned)(fa.hub_wgs + fa.seg_wgs + rows_wgs));
             launch_small_step(lpr, (int)h->segment_unroll, fa, fgrid, s);
             h->last_fused = 1;

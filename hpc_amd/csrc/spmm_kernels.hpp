@@ -705,7 +705,8 @@ __global__ __launch_bounds__(64 * (1 + HubCfg<SW>::L)) void spmm_hub(HubArgs a)
 // rows -- plus, where the longest hub is worth overlapping, a side-stream fork and join of ~20 us: each launch boundary drains the chip and each fork waits for
 // an event to cross queues, and on such steps that IS a third of the time (profiles/r05_report_table.md: time / floor).  Here the three kernels are the three
 // roles of one grid: workgroups [0, hub_wgs) are hub (row, slice) workgroups -- first in the grid, so the longest dependent chain of the step starts first
-// (the hub table is longest-first) --, [hub_wgs, hub_wgs + seg_wgs) take segments (longest first as well), the rest short rows.  No fork, no join, no
+// (the hub table is longest-first) --, [hub_wgs, hub_wgs + seg_wgs) take segments (longest first as well), the rest short rows.  (seg_first: segments, then
+// hubs -- for the steps whose longest SEGMENT lasts longer than their longest hub row: ddi- / collab-shaped.)  No fork, no join, no
 // stream test, one ramp.  Same device functions, same arguments, same arithmetic: same bits.
 // Footprint (make asm, -Rpass-analysis=kernel-resource-usage): the kernel's registers and LDS are the largest role's.  With the chain loop's fixed registers
 // packed from v16 up (gen_hub_chain.py, round 5: they were v32 .. v134, which made the hub role -- and this kernel -- 135 VGPRs, 3 waves per SIMD) the hub role
@@ -716,12 +717,15 @@ struct SmallStepArgs {
     ChunkArgs c;
     RowsArgs r;
     int32_t hub_wgs, seg_wgs;       // workgroups of the first two roles (0: role absent)
+    int32_t seg_first;              // 1: the segment workgroups come first in the grid, then the hub ones ("fused_order": the role whose longest chain LASTS
+                                    // longest starts first -- a 512-nonzero segment at 30 - 47 ns per nonzero outlasts a 5 000-nonzero hub row at 3.2)
 };
 
 template <int LPR, int SEG_UNROLL>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4))) void spmm_small_step(SmallStepArgs a)
 {
-    const int b = (int)blockIdx.x;
+    int b = (int)blockIdx.x;
+    if (a.seg_first && b < a.hub_wgs + a.seg_wgs) b = b < a.seg_wgs ? b + a.hub_wgs : b - a.seg_wgs;     // wave-uniform: the first two roles trade places
     if (b < a.hub_wgs) hub_body<16, false, false>(a.h, b);
     else if (b < a.hub_wgs + a.seg_wgs) chunks_body<4, LPR, SEG_UNROLL, false>(a.c, b - a.hub_wgs, 0);
     else rows_v2_body<4, LPR, 8, false, kPolNtStore, kBlockThreads>(a.r, b - a.hub_wgs - a.seg_wgs, 0);

@@ -159,6 +159,10 @@ const char *mi_spmm_strerror(int code);
  *                         block groups, default cache policy.  auto: only steps whose bytes take under 0.2 ms at 6 TB/s (there the launch
  *                         boundaries are a third of the step; the rows role runs at the hub role's footprint, 3 waves per SIMD).  1: whenever
  *                         eligible.  Same device functions, same arithmetic: same bits.  Read-only "fused_step_in_force": the last run used it
+ *   "fused_order"         0 (default, auto) / 1 / 2: which of the small-step kernel's first two roles leads its grid (workgroups start in blockIdx order):
+ *                         1 = hub workgroups, 2 = segment workgroups.  auto: the role whose longest chain lasts longest -- a hub row at 3.2 ns per
+ *                         nonzero + ~2 us of fill against the longest segment (as long as the hub threshold allows) at 47 ns per nonzero, 30 out of
+ *                         an L2-resident B.  Scheduling only: same bits.  Read-only "fused_order_in_force": 0 (last run not fused) / 1 / 2
  *   "segment_order"       0 (default, auto) / 1: the segment table is sorted longest first (the lane groups of a wave carry similar lengths) / 2: it stays
  *                         in row order (neighbouring rows -- which gather the same B rows where the columns are local -- stay together).  auto = 1: row
  *                         order measured mixed on structured graphs (profiles/r05_regret.md); "autotune" tries it.  Scheduling only

@@ -17,7 +17,7 @@ def host(t): return tuple(torch.from_numpy(x).to(dev) for x in t)
 def ds(name, order): return lambda: synth.csr_dataset_structured_device(name, dev, order=order)
 graphs = {"C1": lambda: host(synth.csr_uniform(1 << 20, 16, 48)), "C2": lambda: host(synth.csr_powerlaw(1 << 20, 32.0, 4096)), "rmat20": lambda: host(synth.csr_rmat(20, 32)),
           "denseish": lambda: host(synth.csr_uniform(1 << 18, 300, 700))}
-for n in ("ppa", "yelp", "youtube", "citation", "products", "protein", "reddit", "wikikg2", "collab", "arxiv", "am"):
+for n in ("ppa", "yelp", "youtube", "citation", "products", "protein", "reddit", "wikikg2", "collab", "arxiv", "am", "ddi"):
     for o in ("shuffled", "degree", "community"):
         graphs[f"{n}-{o}"] = ds(n, o)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -142,7 +142,7 @@ def summarize(path, before=None):
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     worst = []
     short = {"long_row_threshold": "thr", "col_strips": "strips", "tile_cols": "tile", "medium_row_threshold": "mthr", "segment_overlap": "seg_ov", "hub_overlap": "hub_ov",
-             "hub_slice": "slice", "fused_step": "fused", "segment_order": "seg_order", "rows_unroll": "unroll"}
+             "hub_slice": "slice", "fused_step": "fused", "fused_order": "f_order", "segment_order": "seg_order", "rows_unroll": "unroll"}
 
     def fmt(cfg):
         return ", ".join(f"{short.get(k, k)}={'none' if v == NONE_THR else v}" for k, v in cfg.items()) or "(auto)"
@@ -297,7 +297,7 @@ def main():
             # one option at a time from auto: which RULE is at fault when the best forced setting changes several at once
             marg = {}
             for key_, vals_ in (("tile_cols", [t for t in tiles if t]), ("col_strips", strips), ("long_row_threshold", thrs), ("medium_row_threshold", [32, 64, 128, 256, 512, 1024]), ("segment_order", [1, 2]),
-                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else []), ("fused_step", [0, 1]), ("rows_unroll", [16])):
+                                ("segment_overlap", [0, 1]), ("hub_overlap", [0, 2]), ("hub_slice", [16, 32] if acfg["hubs"] > 0 else []), ("fused_step", [0, 1]), ("fused_order", [1, 2]), ("rows_unroll", [16])):
                 for v_ in vals_:
                     consider({key_: v_})
                     ms_, _ = evaluate({key_: v_})
@@ -308,6 +308,9 @@ def main():
                     if tile:
                         base["tile_cols"] = tile
                     consider(base)                       # (fused_step auto: the small-step kernel where eligible)
+                    if S == strips[0]:
+                        for fo in (1, 2):                # the small-step kernel's role order interacts with the hub threshold (which role's chain is the step)
+                            consider(dict(base, fused_order=fo))
                     sep = dict(base, fused_step=0)       # the separate kernels, with the options that only they have
                     consider(sep)
                     for extra in hub_dims(sep):

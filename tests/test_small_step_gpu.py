@@ -146,8 +146,44 @@ def test_small_step_is_the_default_on_short_steps_and_matches_the_reference_kern
     op.preprocess(d_B, d_C)
     op.run(d_B, d_C)
     assert op.get_option("fused_step_in_force") == 1 and op.get_option("n_launches") == 1
+    # "fused_order" auto: arxiv's 12 681-nonzero hub row (40 us of chain) leads its grid; ddi's and collab's 512- / 256-nonzero segments outlast their hub rows
+    assert op.get_option("fused_order_in_force") == (1 if name == "arxiv" else 2), (name, N, op.get_option("fused_order_in_force"))
     if not oracle.ref_available():
         pytest.fail("oracle/_ref missing")
     d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
     oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
     assert count_bitdiff(d_C, d_R) == (0, 0.0)
+
+
+@pytest.mark.parametrize("N", [8, 32, 100, 128])
+def test_small_step_role_order_is_scheduling_only(device, oracle, N):
+    """ "fused_order" 1 (hub workgroups lead the grid) / 2 (segment workgroups lead): the two roles trade blockIdx ranges, nothing else -- the oracle's bits
+    either way, with every role present, with row ranges, and with one of the two roles absent (then there is nothing to trade)."""
+    import torch
+
+    M, K = 2500, 3000
+    ptr, idx = _graph(M, K, seed=300 + N, hubs=(600, 900, 2100))
+    vals = synth.normal_f32(idx.size, 13)
+    Bm = synth.normal_f32(K * N, 14).reshape(K, N)
+    exp = oracle.spmm_omp(ptr, idx, vals, Bm)
+    (d_B,) = to_dev(device, Bm)
+    for order in (1, 2, 0):
+        for opts, hubs in (({"long_row_threshold": 512}, 3), ({"long_row_threshold": 8192}, 0)):
+            op = _op(device, ptr, idx, vals, N, K, dict(opts, fused_step=1, fused_order=order, medium_row_threshold=24))
+            d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+            op.preprocess(d_B, d_C)
+            assert op.get_option("n_hub_rows") == hubs
+            op.run(d_B, d_C)
+            in_force = op.get_option("fused_order_in_force")
+            for r0, r1 in ((0, 700), (700, M)):
+                op.run_rows(d_B, N, d_C, N, r0, r1)
+            torch.cuda.synchronize()
+            assert op.get_option("fused_step_in_force") == 1
+            if order and hubs:
+                assert in_force == order, (N, order, in_force)
+            if not hubs:
+                assert in_force == 1            # no hub role: nothing to put segments in front of
+            got = d_C.cpu().numpy()
+            assert np.array_equal(bits(got), bits(exp)), (N, order, hubs, int((bits(got) != bits(exp)).sum()))
+    with pytest.raises(Exception):
+        op.set_option("fused_order", 3)
