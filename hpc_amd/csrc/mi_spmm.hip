@@ -1375,7 +1375,10 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
         // (local columns: the rows kernel alone is fast and wants its occupancy -- 0.1 ms; columns anywhere: latency-bound whatever the occupancy -- 0.16 ms:
         //  arxiv-community N = 128 loses 18 % fused, arxiv-rcm gains 16 %; youtube-community kLen 32 loses 14 %, youtube-shuffled gains 11 %)
         const double t_fused = h->local_pct >= 50 ? 100e-6 : 160e-6;
-        const bool want = h->fused_step == 1 || (h->fused_step == 2 && (t_bytes < t_fused || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
+        // (a step that is ONE launch anyway -- one role only: ddi-shaped N = 256, every row a segment -- keeps that role's own kernel, which is the better
+        //  instance of it: segments 32 gathers deep instead of 16 at the small-step kernel's footprint; ddi-community kLen 256: 85.7 -> 79 us)
+        const int n_roles = ((h->n_long > 0 && range_has_hub(h, row_begin, row_end)) ? 1 : 0) + (h->n_chunks > 0 ? 1 : 0) + (h->n_rows_for_rows_kernel > 0 ? 1 : 0);
+        const bool want = h->fused_step == 1 || (h->fused_step == 2 && n_roles >= 2 && (t_bytes < t_fused || (double)h->max_row_nnz * 3.2e-9 > t_bytes));
         h->last_fused = 0;
         if (eligible && want) {
             SmallStepArgs fa{};
