@@ -44,11 +44,14 @@ def _separate_kernels_unless_a_test_asks(request):
     # MI_SPMM_TEST_FUSED=1 (scripts/gpu/soak.sh FUSED=1): the other way round -- every eligible step of the fuzz tests goes through the small-step kernel
     # (only the tests that check bits, not launch counts, make sense that way)
     default = 1 if os.environ.get("MI_SPMM_TEST_FUSED") == "1" else 0
+    order = int(os.environ.get("MI_SPMM_TEST_FUSED_ORDER", "0"))      # with it: "fused_order" 1 (hubs lead the grid) / 2 (segments lead) instead of auto
 
     def init(self, *a, **k):
         orig(self, *a, **k)
         try:
             self.set_option("fused_step", default)
+            if order:
+                self.set_option("fused_order", order)
         except Exception:
             pass
 
