@@ -75,7 +75,7 @@ struct mi_spmm_handle {
     // under a handful of forced settings of the options the caller left to us -- tile width, strip count, medium threshold, one launch or several -- and the
     // fastest is kept.  Scheduling only: whatever wins gives the same bits.
     int64_t autotune;
-    uint32_t tuned_mask;     // options the tuner set (bit 0 tile_cols, 1 col_strips, 2 medium_thr, 3 fused_step, 4 segment_order): back to auto before the next tuning
+    uint32_t tuned_mask;     // options the tuner set (bit 0 tile_cols, 1 col_strips, 2 medium_thr, 3 fused_step, 4 segment_order, 5 rows_unroll, 6 long_row_threshold): back to auto before the next tuning
     int32_t tune_evals;      // candidate settings timed by the last preprocess
     double tune_auto_ms, tune_best_ms;
     // plan
@@ -766,7 +766,7 @@ int mi_spmm_set_option(mi_spmm_handle *h, const char *key, int64_t v)
     const std::string k(key);
     if (k == "use_graph") return MI_SPMM_EUNSUPPORTED;      // removed in round 5 (it only ever lost: profiles/r05_use_graph_experiment.md); a caller captures run() itself
     else if (k == "medium_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->medium_thr = v > INT32_MAX ? INT32_MAX : v; h->tuned_mask &= ~4u; free_plan(h); }
-    else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; free_plan(h); }
+    else if (k == "long_row_threshold") { if (v < 0) return MI_SPMM_EINVAL; h->long_thr_user = v > INT32_MAX ? INT32_MAX : v; h->long_thr = h->long_thr_user; h->tuned_mask &= ~64u; free_plan(h); }
     else if (k == "split_long_rows") { h->split_long = v ? 1 : 0; free_plan(h); }
     else if (k == "hub_slice") { if (v != 0 && v != 16 && v != 32 && v != 64) return MI_SPMM_EINVAL; h->hub_slice = v; }
     else if (k == "hub_overlap") { if (v < 0 || v > 2) return MI_SPMM_EINVAL; h->hub_overlap = v; free_plan(h); }
@@ -1715,18 +1715,19 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MI_SPMM_ENOMEM; }
-    struct Cfg { int64_t tile, strips, mthr, fused, order, unroll; };
-    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; h->seg_order = c.order; h->rows_unroll = c.unroll; };
+    struct Cfg { int64_t tile, strips, mthr, fused, order, unroll, thr; };
+    auto apply = [&](const Cfg &c) { h->tile_cols = c.tile; h->col_strips = c.strips; h->medium_thr = c.mthr; h->fused_step = c.fused; h->seg_order = c.order; h->rows_unroll = c.unroll; h->long_thr_user = c.thr; };
     // what the caller left to us (an explicit value of the caller's is never touched); the plan of these settings is the one in force
     const bool own_tile = h->tile_cols == 0, own_strips = h->col_strips == 0, own_mthr = h->medium_thr == 0, own_fused = h->fused_step == 2, own_order = h->seg_order == 0;
-    const bool own_unroll = h->rows_unroll == 0;
-    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step, h->seg_order, h->rows_unroll};
+    const bool own_unroll = h->rows_unroll == 0, own_thr = h->long_thr_user == 0 && !h->split_long && h->feat >= 4;
+    Cfg best = {h->tile_cols, h->col_strips, h->medium_thr, h->fused_step, h->seg_order, h->rows_unroll, h->long_thr_user};
     double best_ms = 0.0;
     int rc = time_step(h, d_vin, d_vout, e0, e1, &best_ms);
     h->tune_auto_ms = best_ms;
     h->tune_evals = 0;
     const int32_t N = h->feat, S_auto = h->n_strips, tile_auto = h->last_lpr * 4, mthr_auto = (int32_t)h->medium_res;
     const bool fused_auto = h->last_fused != 0;
+    const int64_t thr_auto = h->long_thr;        // the resolved hub threshold of the auto plan (1 << 30: the hub fold; 8192 with no row above it: no hubs)
     auto consider = [&](Cfg c) {
         if (rc != MI_SPMM_OK) return;
         apply(c);
@@ -1738,6 +1739,10 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         if (ms < 0.97 * best_ms) { best = c; best_ms = ms; }    // 3 %: a candidate has to beat the noise of a 1 ms measurement
     };
     // one option at a time, each sweep starting from the best so far (the options interact little once the plan class is fixed: scripts/regret.py)
+    // the hub threshold one notch down and one up (a power-of-two ladder, 256 ... 8192): half of auto is 5 - 10 % faster on yelp- / youtube-shaped graphs and an
+    // R-MAT of scale 18, 4 - 15 % slower on ddi- / protein-shaped ones and an R-MAT of scale 20 -- no plan statistic separates them (profiles/r05_regret*.md)
+    if (own_thr && thr_auto >= 256 && thr_auto <= 8192 && h->max_row_nnz > 256)
+        for (int64_t t : {thr_auto / 2, thr_auto * 2}) if (t >= 256 && t <= 8192 && (t < thr_auto || h->max_row_nnz > thr_auto)) { Cfg c = best; c.thr = t; consider(c); }
     if (own_mthr) for (int64_t m : {32, 64, 256, 1024}) if (m != mthr_auto) { Cfg c = best; c.mthr = m; consider(c); }
     if (own_strips) {
         const int64_t cand[3] = {1, S_auto > 1 ? (S_auto / 2 > 1 ? S_auto / 2 : 2) : 4, S_auto > 1 ? (2 * S_auto < kMaxColStrips ? 2 * S_auto : kMaxColStrips) : 12};
@@ -1751,10 +1756,10 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     if (own_unroll && h->last_fused == 0) { Cfg c = best; c.unroll = 16; consider(c); }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step, own_order ? 0 : h->seg_order, own_unroll ? 0 : h->rows_unroll}); return rc; }
+    if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step, own_order ? 0 : h->seg_order, own_unroll ? 0 : h->rows_unroll, own_thr ? 0 : h->long_thr_user}); return rc; }
     apply(best);
     h->tuned_mask = (own_tile && best.tile != 0 ? 1u : 0u) | (own_strips && best.strips != 0 ? 2u : 0u) | (own_mthr && best.mthr != 0 ? 4u : 0u) |
-                    (own_fused && best.fused != 2 ? 8u : 0u) | (own_order && best.order != 0 ? 16u : 0u) | (own_unroll && best.unroll != 0 ? 32u : 0u);
+                    (own_fused && best.fused != 2 ? 8u : 0u) | (own_order && best.order != 0 ? 16u : 0u) | (own_unroll && best.unroll != 0 ? 32u : 0u) | (own_thr && best.thr != 0 ? 64u : 0u);
     h->tune_best_ms = best_ms;
     return preprocess_plan(h);              // the winner's plan (also when the winner is the auto plan: the last candidate's tables are in place otherwise)
 }
@@ -1769,6 +1774,7 @@ int mi_spmm_preprocess(mi_spmm_handle *h, const float *d_vin, float *d_vout)
         if (h->tuned_mask & 8u) h->fused_step = 2;
         if (h->tuned_mask & 16u) h->seg_order = 0;
         if (h->tuned_mask & 32u) h->rows_unroll = 0;
+        if (h->tuned_mask & 64u) h->long_thr_user = 0;
         h->tuned_mask = 0;
     }
     const int rc = preprocess_plan(h);

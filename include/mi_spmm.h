@@ -173,7 +173,7 @@ const char *mi_spmm_strerror(int code);
  *   "autotune"            0 (default) / 1: the rules behind the options above are guesses from a row sample and a histogram, and a wrong guess is silent
  *                         (same bits, slower).  With 1, preprocess MEASURES instead: the step is timed on the vin / vout it is given -- vout is written,
  *                         as the reference's preprocess does (spmm_opt.cu:67) -- under the auto plan and under a dozen forced settings of the options the
- *                         caller left at auto ("medium_row_threshold", "col_strips", "tile_cols", "fused_step", "segment_order", "rows_unroll"; an explicit value of the caller's is
+ *                         caller left at auto ("long_row_threshold" one notch down / up, "medium_row_threshold", "col_strips", "tile_cols", "fused_step", "segment_order", "rows_unroll"; an explicit value of the caller's is
  *                         never touched), one option at a time, and the fastest is kept (it has to win by 3 %).  Costs a dozen plans and ~50 steps of
  *                         preprocess time; scheduling only: same bits.  Afterwards the tuned options read back their chosen values; read-only
  *                         "autotune_evals", "autotune_auto_us", "autotune_best_us", "autotune_mask" (bit 0 tile, 1 strips, 2 medium, 3 fused, 4 segment order, 5 rows unroll: what it changed)

@@ -1748,6 +1748,16 @@ def test_autotune_measures_keeps_the_callers_values_and_every_bit(device, oracle
     op.run(d_B, d_C)
     torch.cuda.synchronize()
     assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
+    # the hub threshold is the tuner's to move one notch (mask bit 6) only while the caller left it at auto
+    op2 = SpMMOpt(CSR(M, idx.size, d_ptr, d_idx, d_val), N)
+    op2.set_option("autotune", 1)
+    op2.set_option("long_row_threshold", 2048)
+    op2.preprocess(d_B, d_C)
+    assert not (op2.get_option("autotune_mask") & 64) and op2.get_option("long_row_threshold") == 2048 and op2.get_option("n_hub_rows") == 2
+    d_C.fill_(float("nan"))
+    op2.run(d_B, d_C)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_C.cpu().numpy()), bits(exp))
 
 
 @pytest.mark.gpu
