@@ -70,6 +70,7 @@ struct mi_spmm_handle {
     int32_t last_fused;      // 1: the last run call went through the small-step kernel
     int64_t fused_order;     // "fused_order": 0 (default) = auto, 1 = hub workgroups first in the small-step grid, 2 = segment workgroups first
     int32_t last_seg_first;  // 1: the last small-step launch put its segment workgroups first
+    int32_t last_rows_deep;  // 1: the last rows launch kept 16 gathers in flight per lane group
     // "autotune" (round 5): the rules above are guesses from a 8 192-row sample and a histogram; a wrong guess is silent (same bits, slower).  With the option on,
     // preprocess MEASURES: the step is timed on the buffers it is given (the reference's preprocess touches vout too: spmm_opt.cu:67) under the auto plan and
     // under a handful of forced settings of the options the caller left to us -- tile width, strip count, medium threshold, one launch or several -- and the
@@ -860,6 +861,7 @@ int mi_spmm_get_option(const mi_spmm_handle *h, const char *key, int64_t *value)
     else if (k == "autotune_mask") *value = h->tuned_mask;
     else if (k == "fused_step_in_force") *value = h->last_fused;
     else if (k == "fused_order") *value = h->fused_order;
+    else if (k == "rows_unroll_in_force") *value = h->last_rows_deep ? 16 : 8;
     else if (k == "fused_order_in_force") *value = h->last_fused ? (h->last_seg_first ? 2 : 1) : 0;
     else if (k == "segment_nnz") *value = h->seg_nnz;
     else if (k == "col_strips_table_hash") {           // FNV-1a over the strip tables (copied back: a test's question, not a step's)
@@ -1575,10 +1577,17 @@ static int run_part(mi_spmm_handle *h, const float *d_vin, int64_t ldb, float *d
     a.flags = flags | (blocks_fallback ? kFlagBlockFallback : 0);
     a.po = po;
     dim3 grid((unsigned)nblk64, col_tiles);
+    // Gathers in flight per lane group, auto: 8 -- except where the rows kernel carries LONG rows one wave per row: banded columns (the only plans that keep
+    // rows of hundreds of nonzeros here: medium threshold 1 024), ONE whole-wave column tile (N = 193 ... 256: at N = 512 the second tile's wave shares the
+    // row's B rows and 16 gains nothing) and a mean degree >= 256.  Then a row is one wave's chain of round trips and 16 halves them: banded 300-700 rows
+    // 0.89 (band +-2048) / 0.90 (+-512), 600-1000 rows 0.93; mean degree 150 and below: 0.98 ... 1.06 (profiles/r05_banded_unroll_ab.jsonl)
+    const bool deep_rows = h->rows_unroll == 16 || (h->rows_unroll == 0 && h->local_pct >= 95 && lpr == 64 && col_tiles == 1 && h->medium_res >= 512 &&
+                                                    M > 0 && h->nnz / M >= 256);
+    h->last_rows_deep = deep_rows && vec4 && !wide && bt == kBlockThreads && pol == kPolNtStore ? 1 : 0;
     // every row may already be owned by the segment, split and block paths: nothing left to launch
     const bool rows_needed = !((blocks_on || h->n_blk_groups == 0) && h->n_rows_for_rows_kernel == 0);
     if (!rows_needed) { /* skip */ }
-    else if (h->rows_unroll == 16 && vec4 && !wide && bt == kBlockThreads && pol == kPolNtStore) launch_rows_v2_deep(lpr, a, grid, s);
+    else if (deep_rows && vec4 && !wide && bt == kBlockThreads && pol == kPolNtStore) launch_rows_v2_deep(lpr, a, grid, s);
     else launch_rows_v2_any(vec4, wide, lpr, bt, pol, a, grid, s);
     if (rows_needed) ++launches;
 
@@ -1726,7 +1735,7 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     h->tune_auto_ms = best_ms;
     h->tune_evals = 0;
     const int32_t N = h->feat, S_auto = h->n_strips, tile_auto = h->last_lpr * 4, mthr_auto = (int32_t)h->medium_res;
-    const bool fused_auto = h->last_fused != 0;
+    const bool fused_auto = h->last_fused != 0, rows_deep_auto = h->last_rows_deep != 0;
     const int64_t thr_auto = h->long_thr;        // the resolved hub threshold of the auto plan (1 << 30: the hub fold; 8192 with no row above it: no hubs)
     auto consider = [&](Cfg c) {
         if (rc != MI_SPMM_OK) return;
@@ -1753,7 +1762,7 @@ static int autotune_plan(mi_spmm_handle *h, const float *d_vin, float *d_vout)
     if (own_order && h->n_chunks > 0) { Cfg c = best; c.order = 2; consider(c); }        // segments as the rows come (auto: by length)
     // 16 gathers in flight per lane group of the rows kernel (auto: 8): -13 % on banded 300-700 rows at N = 256, -8 % on rows of 4 - 12 at N = 128 / 256,
     // -1 % on C1 / C2, +4 ... +23 % on community-ordered graphs (occupancy): no rule of the plan's statistics separates them (profiles/r05_rows_unroll_ab.txt)
-    if (own_unroll && h->last_fused == 0) { Cfg c = best; c.unroll = 16; consider(c); }
+    if (own_unroll && !fused_auto) { Cfg c = best; c.unroll = rows_deep_auto ? 8 : 16; consider(c); }      // (the other depth than the rule's)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != MI_SPMM_OK) { apply({own_tile ? 0 : h->tile_cols, own_strips ? 0 : h->col_strips, own_mthr ? 0 : h->medium_thr, own_fused ? 2 : h->fused_step, own_order ? 0 : h->seg_order, own_unroll ? 0 : h->rows_unroll, own_thr ? 0 : h->long_thr_user}); return rc; }

@@ -166,10 +166,11 @@ const char *mi_spmm_strerror(int code);
  *   "segment_order"       0 (default, auto) / 1: the segment table is sorted longest first (the lane groups of a wave carry similar lengths) / 2: it stays
  *                         in row order (neighbouring rows -- which gather the same B rows where the columns are local -- stay together).  auto = 1: row
  *                         order measured mixed on structured graphs (profiles/r05_regret.md); "autotune" tries it.  Scheduling only
- *   "rows_unroll"         0 (default, auto = 8) / 8 / 16: B-row gathers a lane group of the rows kernel keeps in flight per batch of its row's chain (16 only
+ *   "rows_unroll"         0 (default, auto: 8; 16 for banded columns with a mean degree >= 256 at one whole-wave column tile) / 8 / 16: B-row gathers a lane group of the rows kernel keeps in flight per batch of its row's chain (16 only
  *                         on the plain path: 4-float lanes, 32-bit offsets, 256-thread workgroups, default cache policy; elsewhere 8 stays in force).  16 halves
- *                         the round trips of a row and costs occupancy: -13 % ... +23 % by graph, no rule separates them (profiles/r05_rows_unroll_ab.txt), so
- *                         auto stays 8 and "autotune" tries 16.  Same chain per row: same bits
+ *                         the round trips of a row and costs occupancy: -13 % ... +23 % by graph (profiles/r05_rows_unroll_ab.txt); the one class a plan statistic
+ *                         separates is the banded long-row one (profiles/r05_banded_unroll_ab.jsonl); "autotune" tries the other depth.  Same chain per row:
+ *                         same bits.  Read-only "rows_unroll_in_force": 8 / 16 of the last rows launch
  *   "autotune"            0 (default) / 1: the rules behind the options above are guesses from a row sample and a histogram, and a wrong guess is silent
  *                         (same bits, slower).  With 1, preprocess MEASURES instead: the step is timed on the vin / vout it is given -- vout is written,
  *                         as the reference's preprocess does (spmm_opt.cu:67) -- under the auto plan and under a dozen forced settings of the options the

@@ -417,3 +417,36 @@ def test_structured_graphs_default_options_bit_identical_to_reference_kernel(dev
     d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
     oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
     assert count_bitdiff(d_C, d_R) == (0, 0.0), name
+
+
+@pytest.mark.parametrize("N,deep", [(256, 16), (200, 16), (128, 8), (512, 8)])
+def test_banded_long_rows_rows_kernel_depth_rule_against_the_reference_kernel(device, oracle, N, deep):
+    """ "rows_unroll" auto: banded columns keep rows of hundreds of nonzeros in the rows kernel (medium threshold 1 024); with ONE whole-wave column tile a row is
+    one wave's chain of round trips and the rule keeps 16 gathers in flight (profiles/r05_banded_unroll_ab.jsonl: 0.89 - 0.93 of the time), elsewhere 8.
+    Scheduling only: whole C against spmm_kernel_ref either way, and the caller's explicit 8 is left alone."""
+    import torch
+    from hpc_amd import CSR, SpMMOpt
+    from hpc_amd.spmm import count_bitdiff, fill_normal
+
+    M = 1 << 15
+    d_ptr, d_idx = synth.csr_banded_long_rows_device(M, device, width=1024, lo=300, hi=700, seed=21)
+    nnz = int(d_idx.numel())
+    d_val = torch.empty(nnz, dtype=torch.float32, device=device)
+    fill_normal(d_val, 124, 0, 0.0, 0.1)
+    d_B = torch.empty(M * N, dtype=torch.float32, device=device)
+    fill_normal(d_B, 125, 0, 0.0, 0.1)
+    d_B = d_B.view(M, N)
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref missing")
+    d_R = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+    oracle.ref_kernel_run(d_ptr, d_idx, d_val, d_B, d_R, M, N)
+    for forced in (0, 8):
+        d_C = torch.full((M, N), float("nan"), dtype=torch.float32, device=device)
+        op = SpMMOpt(CSR(M, nnz, d_ptr, d_idx, d_val), N)
+        op.set_option("rows_unroll", forced)
+        op.preprocess(d_B, d_C)
+        assert op.get_option("column_locality_pct") >= 95 and op.get_option("n_chunks") == 0 and op.get_option("medium_row_threshold") == 1024
+        op.run(d_B, d_C)
+        torch.cuda.synchronize()
+        assert op.get_option("rows_unroll_in_force") == (deep if forced == 0 else 8), (N, forced, op.get_option("rows_unroll_in_force"))
+        assert count_bitdiff(d_C, d_R) == (0, 0.0)
