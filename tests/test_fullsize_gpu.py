@@ -428,7 +428,7 @@ def test_banded_long_rows_rows_kernel_depth_rule_against_the_reference_kernel(de
     from hpc_amd import CSR, SpMMOpt
     from hpc_amd.spmm import count_bitdiff, fill_normal
 
-    M = 1 << 15
+    M = 1 << 16                  # (the banded medium-threshold rule starts at 65 536 rows)
     d_ptr, d_idx = synth.csr_banded_long_rows_device(M, device, width=1024, lo=300, hi=700, seed=21)
     nnz = int(d_idx.numel())
     d_val = torch.empty(nnz, dtype=torch.float32, device=device)
