@@ -22,9 +22,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(files):
+    """gpurun MERGES what a call wrote into gpurun_out/: a directory profiled twice holds both passes' files (<pid>_*.csv).  Only the newest pass counts --
+    two passes summed would double every per-step figure."""
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def counters(d, sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if sub in r["Kernel_Name"]:
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -37,7 +43,7 @@ def main():
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     summary = {"tag": tag, "kernel_filter": sub, "steps": steps, "kernels": {}}
-    ks = glob.glob(os.path.join(base + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    ks = newest(glob.glob(os.path.join(base + "_stats", "**", "*kernel_stats.csv"), recursive=True))
     if ks:
         shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
         for r in csv.DictReader(open(ks[0])):
