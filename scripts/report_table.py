@@ -54,16 +54,21 @@ def gather_rate(b_bytes):
 
 def gather_rate_whole(b_bytes):
     """The rate at which B can be gathered WHOLE (no column strips: rows too short to cut into sub-segments of >= 20 nonzeros) -- the guide's measured tiers
-    (MI355X_MICROARCH.md "Indexed rows"): a table every XCD's 4 MiB L2 holds 16.8 - 18.8 TB/s, a 38 MB table of random rows (Infinity Cache) 8.6,
-    151 MB 7.4 - 7.9, HBM 8 at best.  The tighter bound for the entries without strips; gather_rate() stays the bound for any schedule."""
-    return 18e12 if b_bytes <= 4 * 1048576.0 else (8.6e12 if b_bytes <= 256 * 1048576.0 else 8e12)
+    (MI355X_MICROARCH.md "Indexed rows"): rows every XCD's 4 MiB L2 holds 16.8 - 18.8 TB/s (18 here), a 38 MB table of random rows (Infinity Cache) 8.6,
+    151 MB 7.4 - 7.9, HBM 8 at best; a B of b bytes has 4 MiB / b of its gathers served at the L2's rate ("An XCD's 4 MiB L2 holds 4 MiB / T of a uniformly
+    gathered table").  The tighter bound for the entries without strips; gather_rate() stays the bound for any schedule.  (Not strict for an L2-resident B:
+    the CUs' L1s add hits on its hot rows -- ddi-shaped kLen 256, a 4.4 MB B, runs at 20 TB/s on the gather model.)"""
+    f = min(1.0, 4 * 1048576.0 / max(b_bytes, 1.0))
+    slow = 8.6e12 if b_bytes <= 256 * 1048576.0 else 8e12
+    return 1.0 / (f / 18e12 + (1.0 - f) / slow)
 
 
 def floor_seconds(M, N, nnz, longest, whole=False):
     """What no stored-order kernel on this chip goes below: the longest row's dependent chain (3.2 ns per nonzero in the hub kernel; the hardware floor
     is ~5 cycles = 2.1 ns), the gather-model bytes at the rate the size of B allows, one kernel launch (~5 us from enqueue to completion)."""
     bytes_alg = 8.0 * nnz + 4.0 * (M + 1) + 4.0 * N * nnz + 4.0 * M * N
-    return max(longest * 3.2e-9, bytes_alg / (gather_rate_whole if whole else gather_rate)(4.0 * M * N), 5e-6)
+    rate = min(gather_rate_whole(4.0 * M * N), gather_rate(4.0 * M * N)) if whole else gather_rate(4.0 * M * N)      # (never above the any-schedule rate)
+    return max(longest * 3.2e-9, bytes_alg / rate, 5e-6)
 
 
 def main():
