@@ -157,7 +157,7 @@ const char *mi_spmm_strerror(int code);
  *                         take their role from blockIdx, hub slices first so that the step's longest chain starts first) instead of two or three
  *                         launches plus a side-stream fork and join.  Eligible: one column tile (N <= 256), no column strips, no split rows, no
  *                         block groups, default cache policy.  auto: only steps with at least two of the three roles present whose bytes take under 0.1 - 0.16 ms at 6 TB/s (there the launch
- *                         boundaries are a third of the step; the rows role runs at the hub role's footprint, 3 waves per SIMD).  1: whenever
+ *                         boundaries are a third of the step; every role runs at the kernel's footprint, 128 VGPRs = 4 waves per SIMD).  1: whenever
  *                         eligible.  Same device functions, same arithmetic: same bits.  Read-only "fused_step_in_force": the last run used it
  *   "fused_order"         0 (default, auto) / 1 / 2: which of the small-step kernel's first two roles leads its grid (workgroups start in blockIdx order):
  *                         1 = hub workgroups, 2 = segment workgroups.  auto: the role whose longest chain lasts longest -- a hub row at 3.2 ns per
