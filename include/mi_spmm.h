@@ -177,7 +177,7 @@ const char *mi_spmm_strerror(int code);
  *                         caller left at auto ("long_row_threshold" one notch down / up, "medium_row_threshold", "col_strips", "tile_cols", "fused_step", "segment_order", "rows_unroll"; an explicit value of the caller's is
  *                         never touched), one option at a time, and the fastest is kept (it has to win by 3 %).  Costs a dozen plans and ~50 steps of
  *                         preprocess time; scheduling only: same bits.  Afterwards the tuned options read back their chosen values; read-only
- *                         "autotune_evals", "autotune_auto_us", "autotune_best_us", "autotune_mask" (bit 0 tile, 1 strips, 2 medium, 3 fused, 4 segment order, 5 rows unroll: what it changed)
+ *                         "autotune_evals", "autotune_auto_us", "autotune_best_us", "autotune_mask" (bit 0 tile, 1 strips, 2 medium, 3 fused, 4 segment order, 5 rows unroll, 6 hub threshold: what it changed)
  *   ("use_graph", round 4 -- the handle capturing its own launch set into a HIP graph and replaying it -- was removed in round 5: it lost on every graph,
  *    launched on the caller's stream or on a tested stream of its own, profiles/r05_use_graph_experiment.md; the key answers MI_SPMM_EUNSUPPORTED.  run()
  *    allocates nothing and synchronises nothing, so a caller can still capture it into a graph of its own: test_run_is_graph_capturable_and_stream_ordered.)
